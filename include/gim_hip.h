@@ -1,0 +1,166 @@
+/* libgim_hip.so — C ABI of the MI355X (gfx950) kernels behind the GIM image training hot path.
+ *
+ * The reference (roymor1/OptimalStrategiesAgainstGenerativeAttacks) is pure Python/PyTorch and has NO
+ * native layer: every entry point below replaces a torch primitive *call site* of the reference's hot
+ * path (cited per function as file:line relative to the reference root).  The binding a maintainer
+ * adds on the reference side is a ctypes stub, shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers (fp32 unless noted); no torch types;
+ *  - activations are NHWC ([N][H][W][C], C fastest); conv weights are [Cout][KH][KW][Cin]
+ *    (= the reference's [Cout,Cin,KH,KW] parameter stored channels-last); linear weights are [out][in];
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing, owns
+ *    nothing, keeps no global mutable state and is safe to capture into a hipGraph;
+ *  - spatial sizes H, W are powers of two (the reference's Encoder/EnvDecoder require img_size = 2^k,
+ *    models/gim_img_models.py:30,72);
+ *  - return 0 on success, negative GIM_E_* otherwise; gim_last_error() gives a message.
+ */
+#ifndef GIM_HIP_H
+#define GIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIM_OK 0
+#define GIM_E_BADARG (-1)
+#define GIM_E_LAUNCH (-2)
+
+const char* gim_last_error(void);
+int gim_version(void);
+
+/* Shape of one stride-1 'same' convolution (KH x KH, pad = (KH-1)/2) with the fused prologue
+ * x~ = nearest_up2^ups( leaky_relu(x, pre_slope) ); pre_slope = 1 disables the activation.
+ * H, W are the OUTPUT spatial size; the stored input is [N][H>>ups][W>>ups][Cin]. */
+typedef struct {
+    int32_t N, H, W, Cin, Cout, KH, ups;
+    float pre_slope;
+} gim_conv_shape;
+
+/* y = conv(x~, w) / sigma + bias + residual.
+ * Replaces F.conv2d behind nn.Conv2d + spectral_norm (models/model_blocks.py:492-495,522-526,744-750,
+ * 792-793,836-840), the LeakyReLU in front of it (:505,507,764,768,810,856,860), nn.Upsample (:759,765,
+ * 851,857), the residual adds (:512,771,813,863) and nn.Linear (H=W=KH=1; :86,89,786-789,830-833).
+ * sigma (device scalar, may be NULL = 1), bias [Cout] (may be NULL), residual [N,H,W,Cout] (may be NULL). */
+int gim_conv2d_fwd(const float* x, const float* w, const float* bias, const float* sigma, const float* residual,
+                   float* y, const gim_conv_shape* s, void* stream);
+
+/* dx~ = conv_transpose(dy, w) / sigma, at the OUTPUT resolution [N,H,W,Cin] (autograd of the call sites
+ * above w.r.t. the input).  If mask_x != NULL (only legal for ups == 0) the result is multiplied by
+ * leaky_relu'(mask_x) with slope pre_slope, i.e. it is the gradient w.r.t. the raw input x.
+ * For ups == 1 follow with gim_upsample2x_bwd. */
+int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
+                     const gim_conv_shape* s, void* stream);
+
+/* Split-K weight gradient: slabs[i] ([Cout][KH][KW][Cin] each) for i < n_slabs hold partial sums over
+ * disjoint pixel ranges of  dy^T * im2col(x~).  n_slabs from gim_conv2d_wgrad_slabs(). */
+int gim_conv2d_wgrad_slabs(const gim_conv_shape* s);
+int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, int n_slabs, const gim_conv_shape* s, void* stream);
+
+/* Finish a weight gradient: g = sum_i slabs[i];
+ *   sigma == NULL : dw = g                                   (plain nn.Linear weight)
+ *   else          : dw = g / sigma - (<g, w> / sigma^2) u v^T (autograd through torch spectral_norm's
+ *                   weight = weight_orig / (u^T W v) with u, v constants).
+ * u [Cout]; v [Cin*KH*KW] in the REFERENCE's flattening order (ci, kh, kw).  scratch: >= 512 floats. */
+int gim_wgrad_finish(const float* slabs, int n_slabs, const float* w, const float* sigma, const float* u, const float* v,
+                     float* dw, float* scratch, int Cout, int Cin, int KH, void* stream);
+
+/* One power iteration of torch.nn.utils.spectral_norm (n_power_iterations=1, eps=1e-12, dim=0):
+ *   v <- normalize(W^T u); u <- normalize(W v); sigma = u^T W v.       (training = 1)
+ *   sigma = u^T W v with the stored u, v.                               (training = 0)
+ * u [Cout] and v [Cin*KH*KW] (reference order) are updated in place when training; u_out / v_out receive
+ * copies of the vectors used for sigma (saved for backward). scratch: >= 9*Cin*KH*KW + Cout floats. */
+int gim_spectral_sigma(const float* w, float* u, float* v, float* sigma, float* u_out, float* v_out, float* scratch,
+                       int Cout, int Cin, int KH, int training, void* stream);
+
+/* Column sums: out[c] = sum_r x[r][c]  (bias gradients; rows x C). scratch >= 256*C floats. */
+int gim_colsum(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream);
+
+/* Instance norm / AdaIN over H*W per (n, c) on NHWC data.
+ *  mode 0: nn.InstanceNorm2d(affine=True), biased var, eps inside the sqrt (models/gim_img_models.py:126,
+ *          models/model_blocks.py:747-748);  scale/shift are [C].
+ *  mode 1: ada_in (models/model_blocks.py:611-630): unbiased std, eps added to the std; scale/shift are [N][C].
+ * y = scale * (x - mean) / d + shift (+ residual).  stats [N][C][3] = {mean, 1/d, c2} saved for backward. */
+int gim_norm_fwd(const float* x, const float* scale, const float* shift, const float* residual, float* y, float* stats,
+                 int N, int HW, int C, int mode, float eps, void* stream);
+/* dx, and per-(n,c) partials dscale_nc = sum dy*xhat, dshift_nc = sum dy  ([N][C] each). */
+int gim_norm_bwd(const float* dy, const float* x, const float* scale, const float* stats, float* dx, float* dscale_nc,
+                 float* dshift_nc, int N, int HW, int C, int mode, void* stream);
+
+/* 2x2 average pool (nn.AvgPool2d(2), models/model_blocks.py:502,509) NHWC; H, W are the INPUT size. */
+int gim_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int gim_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* Backward of nearest x2 upsampling: dx[n,h,w,c] = sum of the 2x2 block of dy_up; optional
+ * multiplication by leaky_relu'(mask_x) (slope).  H, W are the LOW-resolution size. */
+int gim_upsample2x_bwd(const float* dy_up, const float* mask_x, float slope, float* dx, int N, int H, int W, int C, void* stream);
+
+/* Global spatial max + LeakyReLU (nn.AdaptiveMaxPool2d((1,1)) + LeakyReLU(0.2), models/gim_img_models.py:53-57).
+ * idx [N][C] int32 receives the arg-max pixel (first maximum in row-major scan, as torch). */
+int gim_maxpool_lrelu_fwd(const float* x, float* y, int32_t* idx, int N, int HW, int C, float slope, void* stream);
+int gim_maxpool_lrelu_bwd(const float* dy, const float* y, const int32_t* idx, float* dx, int N, int HW, int C, float slope, void* stream);
+
+/* Batched strided GEMM  C[b](i,j) = sum_k A[b](i,k) * B[b](k,j)  (torch.bmm in SelfAttention,
+ * models/model_blocks.py:539-544 and their autograd).  Element strides; C is row-major [b][M][N]. */
+int gim_bgemm(const float* A, const float* B, float* C, int batch, int M, int N, int K,
+              int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, void* stream);
+
+/* Softmax over dim -2 of [B][R][Ccols] (nn.Softmax(-2), models/model_blocks.py:528,540): columns sum to 1. */
+int gim_softmax_dim1_fwd(const float* s, float* p, int B, int R, int Ccols, void* stream);
+int gim_softmax_dim1_bwd(const float* dp, const float* p, float* ds, int B, int R, int Ccols, void* stream);
+
+/* y = gamma * a + x   (models/model_blocks.py:548), gamma a device scalar.  Backward: da = gamma*dy,
+ * dgamma = sum(dy * a) (device scalar).  scratch: >= 2048 floats. */
+int gim_scale_add_fwd(const float* a, const float* x, const float* gamma, float* y, int64_t n, void* stream);
+int gim_scale_add_bwd(const float* dy, const float* a, const float* gamma, float* da, float* dgamma, float* scratch,
+                      int64_t n, void* stream);
+
+/* tanh (models/gim_img_models.py:215) */
+int gim_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int gim_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
+/* Layout changes at the API boundary: NCHW <-> NHWC for [N][C][H*W]. */
+int gim_nchw_to_nhwc(const float* x, float* y, int N, int C, int HW, void* stream);
+int gim_nhwc_to_nchw(const float* x, float* y, int N, int C, int HW, void* stream);
+
+/* Set statistics of x [B][t][D] (models/gim_basic_models.py:34,51; models/model_blocks.py:41-48):
+ * mean over t and custom_std = sqrt(var_unbiased + 1e-8) (zeros when t == 1), written with row stride
+ * `ld` (so they can land inside the [B][5120] head input, models/gim_img_models.py:297). std may be NULL. */
+int gim_set_stats_fwd(const float* x, float* mean, float* std, int B, int t, int D, int64_t ld_mean, int64_t ld_std, void* stream);
+/* dx = dmean/t + dstd * (x - mean) / ((t-1) * std);  dmean/dstd rows have stride ld_*; either may be NULL. */
+int gim_set_stats_bwd(const float* x, const float* dmean, const float* dstd, float* dx, int B, int t, int D,
+                      int64_t ld_dmean, int64_t ld_dstd, void* stream);
+
+/* BCE-with-logits against a constant target, no reduction (training/gim_img_trainer.py:90-94):
+ * loss = max(x,0) - x*t + log1p(exp(-|x|));  dx = dloss * (sigmoid(x) - t). */
+int gim_bce_logits_fwd(const float* x, float* loss, float target, int n, void* stream);
+int gim_bce_logits_bwd(const float* dloss, const float* x, float* dx, float target, int n, void* stream);
+
+/* y[b][d] = scale * sum_j x[b][j][d]  (x.mean(1), models/gim_img_models.py:289-290,370-371; and the backward
+ * of an expand over the sample dim) and its transpose y[b][j][d] = scale * x[b][d]. */
+int gim_sum_dim1(const float* x, float* y, int B, int t, int D, float scale, void* stream);
+int gim_repeat_dim1(const float* x, float* y, int B, int t, int D, float scale, void* stream);
+
+/* Generator noise combine (models/gim_img_models.py:378-380): y[b][j] = env[b] + w[b][j] - mean_j w[b][j]
+ * (mean term only if remove_mean).  With env == NULL it is also its own backward w.r.t. w. */
+int gim_noise_combine(const float* env, const float* w, float* y, int B, int t, int D, int remove_mean, void* stream);
+
+/* Channel concat of NHWC rows with a broadcast second operand (torch.cat((env_img, expanded_img), dim=2),
+ * models/gim_img_models.py:367,385): a [R][Ca]; b holds R/(P*rep) images of P pixels x Cb channels, each
+ * repeated for `rep` consecutive images of a.  gim_slice_channels is the backward w.r.t. a. */
+int gim_concat2(const float* a, const float* b, float* y, int64_t R, int Ca, int Cb, int P, int rep, void* stream);
+int gim_slice_channels(const float* dy, float* da, int64_t R, int Ca, int Cy, void* stream);
+
+/* Fused multi-tensor Adam on flat buffers (torch.optim.Adam form, no weight decay;
+ * training/gim_img_trainer.py:50-58).  seg_end[n_seg] are exclusive element offsets of the parameter
+ * groups, lr[n_seg] their learning rates (device arrays).  `step` is a device int32 incremented by the call
+ * (graph-replay safe).  grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
+int gim_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end, const float* lr,
+                  int n_seg, float beta1, float beta2, float eps, float grad_scale, int32_t* step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIM_HIP_H */

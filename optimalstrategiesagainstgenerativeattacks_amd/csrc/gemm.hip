@@ -1,0 +1,102 @@
+// Batched strided fp32 GEMM on v_mfma_f32_32x32x2_f32 for the SelfAttention bmm's and their
+// gradients (N = H*W tokens <= 1024, C' = C/8): C[b](i,j) = sum_k A[b](i,k) * B[b](k,j).
+// 64x64 tile per workgroup (4 waves, one 32x32 accumulator each), K step 16.  Arbitrary element
+// strides; the thread->element mapping of each operand follows its unit-stride axis so that global
+// loads stay coalesced for all four transpose combinations.  LDS images are k-major, rows padded to
+// 65 floats so that both fill patterns write conflict-free.
+#include "common.h"
+
+#define GB 64
+#define GK 16
+#define GLD 65
+
+struct BgP {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long long sAb, sAi, sAk, sBb, sBk, sBj;
+};
+
+__global__ __launch_bounds__(256) void bgemm_kernel(const BgP p) {
+    __shared__ float As[2][GK * GLD];
+    __shared__ float Bs[2][GK * GLD];
+    const int t = threadIdx.x;
+    const int i0 = blockIdx.y * GB, j0 = blockIdx.x * GB;
+    const float* A = p.A + (long long)blockIdx.z * p.sAb;
+    const float* B = p.B + (long long)blockIdx.z * p.sBb;
+    const bool a_kfast = (p.sAk == 1);
+    const bool b_jfast = (p.sBj == 1);
+
+    float ra[4], rb[4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = t + 256 * e;
+            int i, k;
+            if (a_kfast) { k = idx & 15; i = idx >> 4; } else { i = idx & 63; k = idx >> 6; }
+            const bool v = (i0 + i) < p.M && (k0 + k) < p.K;
+            ra[e] = v ? A[(long long)(i0 + i) * p.sAi + (long long)(k0 + k) * p.sAk] : 0.f;
+            int j, kb;
+            if (b_jfast) { j = idx & 63; kb = idx >> 6; } else { kb = idx & 15; j = idx >> 4; }
+            const bool vb = (j0 + j) < p.N && (k0 + kb) < p.K;
+            rb[e] = vb ? B[(long long)(k0 + kb) * p.sBk + (long long)(j0 + j) * p.sBj] : 0.f;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = t + 256 * e;
+            int i, k;
+            if (a_kfast) { k = idx & 15; i = idx >> 4; } else { i = idx & 63; k = idx >> 6; }
+            As[buf][k * GLD + i] = ra[e];
+            int j, kb;
+            if (b_jfast) { j = idx & 63; kb = idx >> 6; } else { kb = idx & 15; j = idx >> 4; }
+            Bs[buf][kb * GLD + j] = rb[e];
+        }
+    };
+
+    const int lane = t & 63, r = lane & 31, h = lane >> 5, wv = t >> 6;
+    const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    const int nk = (p.K + GK - 1) / GK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_tiles((ks + 1) * GK);
+#pragma unroll
+        for (int kp = 0; kp < GK / 2; ++kp) {
+            const float a = As[buf][(2 * kp + h) * GLD + wm0 + r];
+            const float b = Bs[buf][(2 * kp + h) * GLD + wn0 + r];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (ks + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    float* C = p.C + (long long)blockIdx.z * p.M * p.N;
+    const int j = j0 + wn0 + r;
+    if (j < p.N) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (i < p.M) C[(long long)i * p.N + j] = acc[e];
+        }
+    }
+}
+
+extern "C" int gim_bgemm(const float* A, const float* B, float* C, int batch, int M, int N, int K, int64_t sAb, int64_t sAi,
+                         int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, void* stream) {
+    GIM_CHECK_ARG(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0, "bgemm: bad args");
+    GIM_CHECK_ARG(batch <= 65535, "bgemm: batch too large for grid.z");
+    BgP p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.sAb = sAb; p.sAi = sAi; p.sAk = sAk; p.sBb = sBb; p.sBk = sBk; p.sBj = sBj;
+    dim3 g((N + GB - 1) / GB, (M + GB - 1) / GB, batch);
+    hipLaunchKernelGGL(bgemm_kernel, g, dim3(256), 0, (hipStream_t)stream, p);
+    return gim_check_launch("gim_bgemm");
+}

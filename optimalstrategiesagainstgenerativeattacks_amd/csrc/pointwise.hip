@@ -1,0 +1,479 @@
+// HBM-bound pointwise / pooling / small-reduction kernels of the GIM hot path (NHWC, fp32).
+#include "common.h"
+
+#define PW_MAX_BLOCKS 2048
+
+static inline int pw_blocks(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > PW_MAX_BLOCKS) b = PW_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+#define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (n); i += (long long)gridDim.x * 256)
+
+// ---------------------------------------------------------------- avg pool 2x2
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long n_out = (long long)N * Ho * Wo * C;
+    GRID_STRIDE(i, n_out) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const float* p = x + (((long long)n * H + 2 * ho) * W + 2 * wo) * C + c;
+        y[i] = 0.25f * (p[0] + p[C] + p[(long long)W * C] + p[(long long)W * C + C]);
+    }
+}
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long n_in = (long long)N * H * W * C;
+    GRID_STRIDE(i, n_in) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        dx[i] = 0.25f * dy[(((long long)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c];
+    }
+}
+extern "C" int gim_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    GIM_CHECK_ARG(x && y && N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && C > 0, "avgpool2_fwd: bad args");
+    const long long n = (long long)N * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
+    return gim_check_launch("gim_avgpool2_fwd");
+}
+extern "C" int gim_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    GIM_CHECK_ARG(dy && dx && N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && C > 0, "avgpool2_bwd: bad args");
+    const long long n = (long long)N * H * W * C;
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C);
+    return gim_check_launch("gim_avgpool2_bwd");
+}
+
+// ---------------------------------------------------------------- nearest x2 upsample backward
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dyu, const float* __restrict__ mx, float slope,
+                                                             float* __restrict__ dx, int N, int H, int W, int C) {
+    const long long n_lo = (long long)N * H * W * C;
+    const int W2 = 2 * W;
+    GRID_STRIDE(i, n_lo) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        const float* p = dyu + (((long long)n * 2 * H + 2 * h) * W2 + 2 * w) * C + c;
+        float g = p[0] + p[C] + p[(long long)W2 * C] + p[(long long)W2 * C + C];
+        if (mx) g *= (mx[i] > 0.f ? 1.0f : slope);
+        dx[i] = g;
+    }
+}
+extern "C" int gim_upsample2x_bwd(const float* dy_up, const float* mask_x, float slope, float* dx, int N, int H, int W, int C, void* stream) {
+    GIM_CHECK_ARG(dy_up && dx && N > 0 && H > 0 && W > 0 && C > 0, "upsample2x_bwd: bad args");
+    const long long n = (long long)N * H * W * C;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy_up, mask_x, slope, dx, N, H, W, C);
+    return gim_check_launch("gim_upsample2x_bwd");
+}
+
+// ---------------------------------------------------------------- global max pool + leaky relu
+__global__ __launch_bounds__(256) void maxpool_lrelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ idx,
+                                                                int HW, int C, float slope) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int n = blockIdx.y, cl = threadIdx.x & 63, hg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (c < C) {
+        const float* xb = x + (long long)n * HW * C + c;
+        for (int i = hg; i < HW; i += 4) {
+            const float v = xb[(long long)i * C];
+            if (v > best || bi == 0x7fffffff) { best = v; bi = i; }
+        }
+    }
+    sv[hg][cl] = best;
+    si[hg][cl] = bi;
+    __syncthreads();
+    if (hg == 0 && c < C) {
+        for (int g = 1; g < 4; ++g) {
+            const float v = sv[g][cl];
+            const int i2 = si[g][cl];
+            if (i2 != 0x7fffffff && (v > best || (v == best && i2 < bi))) { best = v; bi = i2; }
+        }
+        y[(long long)n * C + c] = lrelu_f(best, slope);
+        idx[(long long)n * C + c] = bi;
+    }
+}
+__global__ __launch_bounds__(256) void maxpool_lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const int32_t* __restrict__ idx,
+                                                                float* __restrict__ dx, int N, int HW, int C, float slope) {
+    const long long n_nc = (long long)N * C;
+    GRID_STRIDE(i, n_nc) {
+        const int c = (int)(i % C);
+        const long long n = i / C;
+        dx[(n * HW + idx[i]) * C + c] = dy[i] * (y[i] > 0.f ? 1.0f : slope);
+    }
+}
+extern "C" int gim_maxpool_lrelu_fwd(const float* x, float* y, int32_t* idx, int N, int HW, int C, float slope, void* stream) {
+    GIM_CHECK_ARG(x && y && idx && N > 0 && HW > 0 && C > 0, "maxpool_lrelu_fwd: bad args");
+    hipLaunchKernelGGL(maxpool_lrelu_fwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, y, idx, HW, C, slope);
+    return gim_check_launch("gim_maxpool_lrelu_fwd");
+}
+extern "C" int gim_maxpool_lrelu_bwd(const float* dy, const float* y, const int32_t* idx, float* dx, int N, int HW, int C, float slope, void* stream) {
+    GIM_CHECK_ARG(dy && y && idx && dx && N > 0 && HW > 0 && C > 0, "maxpool_lrelu_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dx, 0, (size_t)N * HW * C * sizeof(float), st) != hipSuccess) return gim_check_launch("maxpool_lrelu_bwd memset");
+    hipLaunchKernelGGL(maxpool_lrelu_bwd_kernel, dim3(pw_blocks((long long)N * C)), dim3(256), 0, st, dy, y, idx, dx, N, HW, C, slope);
+    return gim_check_launch("gim_maxpool_lrelu_bwd");
+}
+
+// ---------------------------------------------------------------- softmax over dim -2 of [B][R][Cc]
+__global__ __launch_bounds__(256) void softmax_dim1_fwd_kernel(const float* __restrict__ s, float* __restrict__ p, int R, int Cc) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const bool ok = col < Cc;
+    const float* sb = s + (long long)b * R * Cc + col;
+    float mx = -INFINITY;
+    if (ok) for (int r = rg; r < R; r += 4) mx = fmaxf(mx, sb[(long long)r * Cc]);
+    red[rg][cl] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][cl], red[1][cl]), fmaxf(red[2][cl], red[3][cl]));
+    __syncthreads();
+    float sum = 0.f;
+    if (ok) for (int r = rg; r < R; r += 4) sum += __expf(sb[(long long)r * Cc] - mx);
+    red[rg][cl] = sum;
+    __syncthreads();
+    sum = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (!ok) return;
+    const float inv = 1.0f / sum;
+    float* pb = p + (long long)b * R * Cc + col;
+    for (int r = rg; r < R; r += 4) pb[(long long)r * Cc] = __expf(sb[(long long)r * Cc] - mx) * inv;
+}
+__global__ __launch_bounds__(256) void softmax_dim1_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p, float* __restrict__ ds, int R, int Cc) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const bool ok = col < Cc;
+    const long long base = (long long)b * R * Cc + col;
+    float dot = 0.f;
+    if (ok) for (int r = rg; r < R; r += 4) dot += dp[base + (long long)r * Cc] * p[base + (long long)r * Cc];
+    red[rg][cl] = dot;
+    __syncthreads();
+    dot = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (!ok) return;
+    for (int r = rg; r < R; r += 4) {
+        const long long o = base + (long long)r * Cc;
+        ds[o] = p[o] * (dp[o] - dot);
+    }
+}
+extern "C" int gim_softmax_dim1_fwd(const float* s, float* p, int B, int R, int Ccols, void* stream) {
+    GIM_CHECK_ARG(s && p && B > 0 && R > 0 && Ccols > 0, "softmax_dim1_fwd: bad args");
+    hipLaunchKernelGGL(softmax_dim1_fwd_kernel, dim3((Ccols + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, s, p, R, Ccols);
+    return gim_check_launch("gim_softmax_dim1_fwd");
+}
+extern "C" int gim_softmax_dim1_bwd(const float* dp, const float* p, float* ds, int B, int R, int Ccols, void* stream) {
+    GIM_CHECK_ARG(dp && p && ds && B > 0 && R > 0 && Ccols > 0, "softmax_dim1_bwd: bad args");
+    hipLaunchKernelGGL(softmax_dim1_bwd_kernel, dim3((Ccols + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dp, p, ds, R, Ccols);
+    return gim_check_launch("gim_softmax_dim1_bwd");
+}
+
+// ---------------------------------------------------------------- y = gamma * a + x
+__global__ __launch_bounds__(256) void scale_add_fwd_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            float* __restrict__ y, long long n) {
+    const float g = gamma[0];
+    GRID_STRIDE(i, n) y[i] = g * a[i] + x[i];
+}
+__global__ __launch_bounds__(256) void scale_add_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ gamma,
+                                                            float* __restrict__ da, float* __restrict__ partial, long long n) {
+    __shared__ float red[4];
+    const float g = gamma[0];
+    float dot = 0.f;
+    GRID_STRIDE(i, n) {
+        const float d = dy[i];
+        da[i] = g * d;
+        dot += d * a[i];
+    }
+    dot = block_sum_256(dot, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = dot;
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+extern "C" int gim_scale_add_fwd(const float* a, const float* x, const float* gamma, float* y, int64_t n, void* stream) {
+    GIM_CHECK_ARG(a && x && gamma && y && n > 0, "scale_add_fwd: bad args");
+    hipLaunchKernelGGL(scale_add_fwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, x, gamma, y, (long long)n);
+    return gim_check_launch("gim_scale_add_fwd");
+}
+extern "C" int gim_scale_add_bwd(const float* dy, const float* a, const float* gamma, float* da, float* dgamma, float* scratch,
+                                 int64_t n, void* stream) {
+    GIM_CHECK_ARG(dy && a && gamma && da && dgamma && scratch && n > 0, "scale_add_bwd: bad args");
+    const int blocks = pw_blocks(n);
+    hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, a, gamma, da, scratch, (long long)n);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, blocks, dgamma);
+    return gim_check_launch("gim_scale_add_bwd");
+}
+
+// ---------------------------------------------------------------- tanh
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    GRID_STRIDE(i, n) y[i] = tanhf(x[i]);
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long long n) {
+    GRID_STRIDE(i, n) { const float t = y[i]; dx[i] = dy[i] * (1.0f - t * t); }
+}
+extern "C" int gim_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
+    GIM_CHECK_ARG(x && y && n > 0, "tanh_fwd: bad args");
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n);
+    return gim_check_launch("gim_tanh_fwd");
+}
+extern "C" int gim_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    GIM_CHECK_ARG(dy && y && dx && n > 0, "tanh_bwd: bad args");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (long long)n);
+    return gim_check_launch("gim_tanh_bwd");
+}
+
+// ---------------------------------------------------------------- NCHW <-> NHWC
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int HW) {
+    const long long n_el = (long long)N * C * HW;
+    GRID_STRIDE(i, n_el) {  // i indexes the NHWC output
+        const int c = (int)(i % C);
+        const long long r = i / C;
+        const int hw = (int)(r % HW);
+        const long long n = r / HW;
+        y[i] = x[(n * C + c) * HW + hw];
+    }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int HW) {
+    const long long n_el = (long long)N * C * HW;
+    GRID_STRIDE(i, n_el) {  // i indexes the NCHW output
+        const int hw = (int)(i % HW);
+        const long long r = i / HW;
+        const int c = (int)(r % C);
+        const long long n = r / C;
+        y[i] = x[(n * HW + hw) * C + c];
+    }
+}
+extern "C" int gim_nchw_to_nhwc(const float* x, float* y, int N, int C, int HW, void* stream) {
+    GIM_CHECK_ARG(x && y && N > 0 && C > 0 && HW > 0, "nchw_to_nhwc: bad args");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(pw_blocks((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, HW);
+    return gim_check_launch("gim_nchw_to_nhwc");
+}
+extern "C" int gim_nhwc_to_nchw(const float* x, float* y, int N, int C, int HW, void* stream) {
+    GIM_CHECK_ARG(x && y && N > 0 && C > 0 && HW > 0, "nhwc_to_nchw: bad args");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(pw_blocks((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, HW);
+    return gim_check_launch("gim_nhwc_to_nchw");
+}
+
+// ---------------------------------------------------------------- set statistics over the sample dim
+__global__ __launch_bounds__(256) void set_stats_fwd_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ sd,
+                                                            int B, int t, int D, long long ldm, long long lds) {
+    const long long n = (long long)B * D;
+    GRID_STRIDE(i, n) {
+        const int d = (int)(i % D);
+        const long long b = i / D;
+        const float* xb = x + b * t * D + d;
+        float m = 0.f;
+        for (int j = 0; j < t; ++j) m += xb[(long long)j * D];
+        m /= (float)t;
+        mean[b * ldm + d] = m;
+        if (sd) {
+            float v = 0.f;
+            if (t > 1) {
+                float ss = 0.f;
+                for (int j = 0; j < t; ++j) { const float dd = xb[(long long)j * D] - m; ss += dd * dd; }
+                v = sqrtf(ss / (float)(t - 1) + 1e-8f);
+            }
+            sd[b * lds + d] = v;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void set_stats_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dmean, const float* __restrict__ dsd,
+                                                            float* __restrict__ dx, int B, int t, int D, long long ldm, long long lds) {
+    const long long n = (long long)B * D;
+    GRID_STRIDE(i, n) {
+        const int d = (int)(i % D);
+        const long long b = i / D;
+        const float* xb = x + b * t * D + d;
+        float* db = dx + b * t * D + d;
+        const float gm = dmean ? dmean[b * ldm + d] / (float)t : 0.f;
+        float m = 0.f, coef = 0.f;
+        if (dsd && t > 1) {
+            for (int j = 0; j < t; ++j) m += xb[(long long)j * D];
+            m /= (float)t;
+            float ss = 0.f;
+            for (int j = 0; j < t; ++j) { const float dd = xb[(long long)j * D] - m; ss += dd * dd; }
+            const float sdv = sqrtf(ss / (float)(t - 1) + 1e-8f);
+            coef = dsd[b * lds + d] / ((float)(t - 1) * sdv);
+        }
+        for (int j = 0; j < t; ++j) db[(long long)j * D] = gm + coef * (xb[(long long)j * D] - m);
+    }
+}
+extern "C" int gim_set_stats_fwd(const float* x, float* mean, float* std, int B, int t, int D, int64_t ld_mean, int64_t ld_std, void* stream) {
+    GIM_CHECK_ARG(x && mean && B > 0 && t > 0 && D > 0, "set_stats_fwd: bad args");
+    hipLaunchKernelGGL(set_stats_fwd_kernel, dim3(pw_blocks((long long)B * D)), dim3(256), 0, (hipStream_t)stream, x, mean, std, B, t, D,
+                       (long long)ld_mean, (long long)ld_std);
+    return gim_check_launch("gim_set_stats_fwd");
+}
+extern "C" int gim_set_stats_bwd(const float* x, const float* dmean, const float* dstd, float* dx, int B, int t, int D,
+                                 int64_t ld_dmean, int64_t ld_dstd, void* stream) {
+    GIM_CHECK_ARG(x && dx && B > 0 && t > 0 && D > 0, "set_stats_bwd: bad args");
+    hipLaunchKernelGGL(set_stats_bwd_kernel, dim3(pw_blocks((long long)B * D)), dim3(256), 0, (hipStream_t)stream, x, dmean, dstd, dx, B, t, D,
+                       (long long)ld_dmean, (long long)ld_dstd);
+    return gim_check_launch("gim_set_stats_bwd");
+}
+
+// ---------------------------------------------------------------- BCE with logits, constant target
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, float* __restrict__ loss, float tgt, int n) {
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        loss[i] = fmaxf(v, 0.f) - v * tgt + log1pf(expf(-fabsf(v)));
+    }
+}
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ x, float* __restrict__ dx, float tgt, int n) {
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        const float sg = 1.0f / (1.0f + expf(-v));
+        dx[i] = dl[i] * (sg - tgt);
+    }
+}
+extern "C" int gim_bce_logits_fwd(const float* x, float* loss, float target, int n, void* stream) {
+    GIM_CHECK_ARG(x && loss && n > 0, "bce_logits_fwd: bad args");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, loss, target, n);
+    return gim_check_launch("gim_bce_logits_fwd");
+}
+extern "C" int gim_bce_logits_bwd(const float* dloss, const float* x, float* dx, float target, int n, void* stream) {
+    GIM_CHECK_ARG(dloss && x && dx && n > 0, "bce_logits_bwd: bad args");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, dloss, x, dx, target, n);
+    return gim_check_launch("gim_bce_logits_bwd");
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, float* __restrict__ part, long long rows, int C, long long rows_per) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long long r0 = (long long)blockIdx.y * rows_per;
+    const long long r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
+    float s = 0.f;
+    if (c < C) for (long long r = r0 + rg; r < r1; r += 4) s += x[r * C + c];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) part[(long long)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(long long)p * C + c];
+    out[c] = s;
+}
+extern "C" int gim_colsum(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream) {
+    GIM_CHECK_ARG(x && out && scratch && rows > 0 && C > 0, "colsum: bad args");
+    long long P = (rows + 63) / 64;
+    if (P > 256) P = 256;
+    const long long rows_per = (rows + P - 1) / P;
+    P = (rows + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 63) / 64, (int)P), dim3(256), 0, (hipStream_t)stream, x, scratch, (long long)rows, C, rows_per);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)P, C);
+    return gim_check_launch("gim_colsum");
+}
+
+// ---------------------------------------------------------------- sums / repeats over the sample dim
+// y[b][d] = scale * sum_j x[b][j][d]
+__global__ __launch_bounds__(256) void sum_dim1_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int t, int D, float scale) {
+    const long long n = (long long)B * D;
+    GRID_STRIDE(i, n) {
+        const int d = (int)(i % D);
+        const long long b = i / D;
+        const float* xb = x + b * t * D + d;
+        float s = 0.f;
+        for (int j = 0; j < t; ++j) s += xb[(long long)j * D];
+        y[i] = s * scale;
+    }
+}
+// y[b][j][d] = scale * x[b][d]
+__global__ __launch_bounds__(256) void repeat_dim1_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int t, int D, float scale) {
+    const long long n = (long long)B * t * D;
+    GRID_STRIDE(i, n) {
+        const int d = (int)(i % D);
+        const long long b = i / ((long long)t * D);
+        y[i] = scale * x[b * D + d];
+    }
+}
+extern "C" int gim_sum_dim1(const float* x, float* y, int B, int t, int D, float scale, void* stream) {
+    GIM_CHECK_ARG(x && y && B > 0 && t > 0 && D > 0, "sum_dim1: bad args");
+    hipLaunchKernelGGL(sum_dim1_kernel, dim3(pw_blocks((long long)B * D)), dim3(256), 0, (hipStream_t)stream, x, y, B, t, D, scale);
+    return gim_check_launch("gim_sum_dim1");
+}
+extern "C" int gim_repeat_dim1(const float* x, float* y, int B, int t, int D, float scale, void* stream) {
+    GIM_CHECK_ARG(x && y && B > 0 && t > 0 && D > 0, "repeat_dim1: bad args");
+    hipLaunchKernelGGL(repeat_dim1_kernel, dim3(pw_blocks((long long)B * t * D)), dim3(256), 0, (hipStream_t)stream, x, y, B, t, D, scale);
+    return gim_check_launch("gim_repeat_dim1");
+}
+
+// ---------------------------------------------------------------- generator noise combine
+// fwd: y[b][j] = env[b] + w[b][j] - (remove_mean ? mean_j w[b][j] : 0)
+// bwd (same kernel, env == NULL): dw[b][j] = dy[b][j] - (remove_mean ? mean_j dy[b][j] : 0)
+__global__ __launch_bounds__(256) void noise_combine_kernel(const float* __restrict__ env, const float* __restrict__ w, float* __restrict__ y,
+                                                            int B, int t, int D, int remove_mean) {
+    const long long n = (long long)B * D;
+    GRID_STRIDE(i, n) {
+        const int d = (int)(i % D);
+        const long long b = i / D;
+        const float* wb = w + b * t * D + d;
+        float* yb = y + b * t * D + d;
+        float m = 0.f;
+        if (remove_mean) {
+            for (int j = 0; j < t; ++j) m += wb[(long long)j * D];
+            m /= (float)t;
+        }
+        const float e = env ? env[i] : 0.f;
+        for (int j = 0; j < t; ++j) yb[(long long)j * D] = e + wb[(long long)j * D] - m;
+    }
+}
+extern "C" int gim_noise_combine(const float* env, const float* w, float* y, int B, int t, int D, int remove_mean, void* stream) {
+    GIM_CHECK_ARG(w && y && B > 0 && t > 0 && D > 0, "noise_combine: bad args");
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(pw_blocks((long long)B * D)), dim3(256), 0, (hipStream_t)stream, env, w, y, B, t, D, remove_mean);
+    return gim_check_launch("gim_noise_combine");
+}
+
+// ---------------------------------------------------------------- channel concat with broadcast
+// y[r][0:Ca] = a[r][:],  y[r][Ca:Ca+Cb] = b[(r / rows_per_a_img / rep) ...]: a has R rows of Ca channels, b has
+// R/rep "image blocks": row r of y takes b's row  (r / (P*rep)) * P + (r % P)  with P = pixels per image.
+__global__ __launch_bounds__(256) void concat2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                                      long long R, int Ca, int Cb, int P, int rep) {
+    const int Cy = Ca + Cb;
+    const long long n = R * Cy;
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % Cy);
+        const long long r = i / Cy;
+        if (c < Ca) {
+            y[i] = a[r * Ca + c];
+        } else {
+            const long long img = r / P;
+            const int px = (int)(r - img * P);
+            y[i] = b[((img / rep) * P + px) * Cb + (c - Ca)];
+        }
+    }
+}
+// da[r][c] = dy[r][c] for c < Ca
+__global__ __launch_bounds__(256) void slice_channels_kernel(const float* __restrict__ dy, float* __restrict__ da, long long R, int Ca, int Cy) {
+    const long long n = R * Ca;
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % Ca);
+        const long long r = i / Ca;
+        da[i] = dy[r * Cy + c];
+    }
+}
+extern "C" int gim_concat2(const float* a, const float* b, float* y, int64_t R, int Ca, int Cb, int P, int rep, void* stream) {
+    GIM_CHECK_ARG(a && b && y && R > 0 && Ca > 0 && Cb > 0 && P > 0 && rep > 0, "concat2: bad args");
+    hipLaunchKernelGGL(concat2_kernel, dim3(pw_blocks(R * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)R, Ca, Cb, P, rep);
+    return gim_check_launch("gim_concat2");
+}
+extern "C" int gim_slice_channels(const float* dy, float* da, int64_t R, int Ca, int Cy, void* stream) {
+    GIM_CHECK_ARG(dy && da && R > 0 && Ca > 0 && Cy >= Ca, "slice_channels: bad args");
+    hipLaunchKernelGGL(slice_channels_kernel, dim3(pw_blocks(R * Ca)), dim3(256), 0, (hipStream_t)stream, dy, da, (long long)R, Ca, Cy);
+    return gim_check_launch("gim_slice_channels");
+}

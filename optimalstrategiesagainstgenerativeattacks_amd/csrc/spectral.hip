@@ -1,0 +1,173 @@
+// Spectral-norm power iteration and the weight-gradient finish (HBM-bound GEMV-shaped work).
+//
+// Weight W is [Cout][T][Cin] in memory (T = KH*KH taps); torch's weight_mat is [Cout][Cin*T] with
+// column q = ci*T + tap.  u is [Cout]; v is [Cin*T] in torch's order, so the kernels translate
+// physical column p = tap*Cin + ci  <->  q = ci*T + tap.
+#include "common.h"
+
+#define SN_R 8  // row chunks of the W^T u partial sums
+
+// part[r][p] = sum over the r-th chunk of rows co of W[co][p] * u[co]
+__global__ __launch_bounds__(256) void sn_colpart_kernel(const float* __restrict__ w, const float* __restrict__ u,
+                                                         float* __restrict__ part, int Cout, int K, int rows_per) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    const int c0 = r * rows_per, c1 = min(Cout, c0 + rows_per);
+    if (p >= K) return;
+    float acc = 0.f;
+    for (int co = c0; co < c1; ++co) acc += w[(long long)co * K + p] * u[co];
+    part[(long long)r * K + p] = acc;
+}
+
+// single block.  training: a = sum_r part[r]; v = a / max(|a|, eps) ; else v given.
+// writes v_phys (physical order, scratch), v (torch order, in place when training) and v_out (copy).
+__global__ __launch_bounds__(256) void sn_vnorm_kernel(const float* __restrict__ part, int R, float* __restrict__ v,
+                                                       float* __restrict__ v_phys, float* __restrict__ v_out, int K, int Cin,
+                                                       int T, int training) {
+    __shared__ float red[4];
+    if (training) {
+        float ss = 0.f;
+        for (int p = threadIdx.x; p < K; p += 256) {
+            float a = 0.f;
+            for (int r = 0; r < R; ++r) a += part[(long long)r * K + p];
+            v_phys[p] = a;
+            ss += a * a;
+        }
+        const float nrm = sqrtf(block_sum_256(ss, red));
+        const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+        for (int p = threadIdx.x; p < K; p += 256) {
+            const float val = v_phys[p] * inv;
+            const int tap = p / Cin, ci = p - tap * Cin;
+            const int q = ci * T + tap;
+            v_phys[p] = val;
+            v[q] = val;
+            v_out[q] = val;
+        }
+    } else {
+        for (int q = threadIdx.x; q < K; q += 256) {
+            const int ci = q / T, tap = q - ci * T;
+            const float val = v[q];
+            v_phys[tap * Cin + ci] = val;
+            v_out[q] = val;
+        }
+    }
+}
+
+// t[co] = sum_p W[co][p] * v_phys[p]; one wave per row
+__global__ __launch_bounds__(256) void sn_rowdot_kernel(const float* __restrict__ w, const float* __restrict__ v_phys,
+                                                        float* __restrict__ tvec, int Cout, int K) {
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (co >= Cout) return;
+    float acc = 0.f;
+    const float* row = w + (long long)co * K;
+    for (int p = lane; p < K; p += 64) acc += row[p] * v_phys[p];
+    acc = wave_sum(acc);
+    if (lane == 0) tvec[co] = acc;
+}
+
+// single block. training: u = t / max(|t|, eps); sigma = u . t ; else sigma = u . t with the stored u.
+__global__ __launch_bounds__(256) void sn_final_kernel(const float* __restrict__ tvec, float* __restrict__ u,
+                                                       float* __restrict__ u_out, float* __restrict__ sigma, int Cout,
+                                                       int training) {
+    __shared__ float red[4];
+    float inv = 0.f;
+    if (training) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < Cout; c += 256) ss += tvec[c] * tvec[c];
+        inv = 1.0f / fmaxf(sqrtf(block_sum_256(ss, red)), 1e-12f);
+    }
+    float dot = 0.f;
+    for (int c = threadIdx.x; c < Cout; c += 256) {
+        float uv;
+        if (training) {
+            uv = tvec[c] * inv;
+            u[c] = uv;
+        } else {
+            uv = u[c];
+        }
+        u_out[c] = uv;
+        dot += uv * tvec[c];
+    }
+    dot = block_sum_256(dot, red);
+    if (threadIdx.x == 0) sigma[0] = dot;
+}
+
+extern "C" int gim_spectral_sigma(const float* w, float* u, float* v, float* sigma, float* u_out, float* v_out, float* scratch,
+                                  int Cout, int Cin, int KH, int training, void* stream) {
+    GIM_CHECK_ARG(w && u && v && sigma && u_out && v_out && scratch, "spectral_sigma: null pointer");
+    GIM_CHECK_ARG(Cout > 0 && Cin > 0 && KH > 0, "spectral_sigma: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = KH * KH, K = Cin * T;
+    float* part = scratch;                 // [SN_R][K]
+    float* v_phys = scratch + SN_R * K;    // [K]
+    float* tvec = v_phys + K;              // [Cout]
+    int R = 1;
+    if (training) {
+        R = min(SN_R, (Cout + 63) / 64);
+        const int rows_per = (Cout + R - 1) / R;
+        hipLaunchKernelGGL(sn_colpart_kernel, dim3((K + 255) / 256, R), dim3(256), 0, st, w, u, part, Cout, K, rows_per);
+    }
+    hipLaunchKernelGGL(sn_vnorm_kernel, dim3(1), dim3(256), 0, st, part, R, v, v_phys, v_out, K, Cin, T, training);
+    hipLaunchKernelGGL(sn_rowdot_kernel, dim3((Cout + 3) / 4), dim3(256), 0, st, w, v_phys, tvec, Cout, K);
+    hipLaunchKernelGGL(sn_final_kernel, dim3(1), dim3(256), 0, st, tvec, u, u_out, sigma, Cout, training);
+    return gim_check_launch("gim_spectral_sigma");
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight-gradient finish
+// -------------------------------------------------------------------------------------------------
+#define WF_BLOCKS 512
+
+__global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* __restrict__ slabs, int n_slabs, long long n,
+                                                        const float* __restrict__ w, float* __restrict__ dw,
+                                                        float* __restrict__ partial) {
+    __shared__ float red[4];
+    float dot = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float g = 0.f;
+        for (int s = 0; s < n_slabs; ++s) g += slabs[(long long)s * n + i];
+        dw[i] = g;
+        if (w) dot += g * w[i];
+    }
+    if (partial) {
+        dot = block_sum_256(dot, red);
+        if (threadIdx.x == 0) partial[blockIdx.x] = dot;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_sn_apply_kernel(float* __restrict__ dw, const float* __restrict__ partial, int n_part,
+                                                             const float* __restrict__ sigma, const float* __restrict__ u,
+                                                             const float* __restrict__ v, long long n, int Cin, int T) {
+    __shared__ float red[4];
+    float d = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) d += partial[i];
+    d = block_sum_256(d, red);
+    const float s = sigma[0];
+    const float inv = 1.0f / s;
+    const float coef = d * inv * inv;
+    const int K = Cin * T;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i / K);
+        const int p = (int)(i - (long long)co * K);
+        const int tap = p / Cin, ci = p - tap * Cin;
+        dw[i] = dw[i] * inv - coef * u[co] * v[ci * T + tap];
+    }
+}
+
+extern "C" int gim_wgrad_finish(const float* slabs, int n_slabs, const float* w, const float* sigma, const float* u,
+                                const float* v, float* dw, float* scratch, int Cout, int Cin, int KH, void* stream) {
+    GIM_CHECK_ARG(slabs && dw && n_slabs > 0, "wgrad_finish: bad args");
+    GIM_CHECK_ARG(!sigma || (w && u && v && scratch), "wgrad_finish: spectral form needs w, u, v, scratch");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = KH * KH;
+    const long long n = (long long)Cout * Cin * T;
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > WF_BLOCKS) blocks = WF_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wgrad_sum_kernel, dim3(blocks), dim3(256), 0, st, slabs, n_slabs, n, sigma ? w : nullptr, dw,
+                       sigma ? scratch : nullptr);
+    if (sigma)
+        hipLaunchKernelGGL(wgrad_sn_apply_kernel, dim3(blocks), dim3(256), 0, st, dw, scratch, blocks, sigma, u, v, n, Cin, T);
+    return gim_check_launch("gim_wgrad_finish");
+}

@@ -1,0 +1,276 @@
+"""The GIM image agents on the MI355X engine: host-side mirror of the reference's
+``models/gim_img_models.py`` (same classes, constructor arguments, attribute names, ``get_au`` / ``get_im``
+factories and state-dict keys), every forward running the HIP kernels of ``libgim_hip.so``.
+
+API tensors keep the reference's layout (samples are ``[B, set, C, S, S]``, NCHW); inside, everything is
+NHWC.  ``GIMFaceImpersonator.forward`` takes one extra optional argument ``z`` so that the latent noise
+(drawn inside forward by the reference, gim_img_models.py:374) can be injected for parity tests.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import model_blocks as mb
+from . import ops
+from .gim_basic_models import GIMMeanStdFcStat
+
+
+class Encoder(nn.Module):
+    """models/gim_img_models.py:19-57.  forward: NHWC [N, S, S, C] -> [N, style_dim]."""
+
+    def __init__(self, img_size, img_channels, style_dim=512, min_n_channels=64, use_out_lrelu=True):
+        super().__init__()
+        assert use_out_lrelu, "the hot path fuses the output LeakyReLU into the max-pool kernel"
+        self.img_size, self.img_channels, self.style_dim = img_size, img_channels, style_dim
+        self.use_out_lrelu = use_out_lrelu
+        self.n_down_blocks = int(math.log2(img_size)) - 2
+        self.min_n_channels = int(max(min_n_channels, style_dim / (2 ** (self.n_down_blocks - 1))))
+        self.channel_sizes = [img_channels] + [min(style_dim, int(self.min_n_channels * (2 ** i)))
+                                               for i in range(self.n_down_blocks)]
+        self.att_loc = int(math.ceil(self.n_down_blocks / 2))
+        self.down_blocks = nn.ModuleList()
+        for i in range(self.n_down_blocks):
+            self.down_blocks.append(mb.ResBlockDown(self.channel_sizes[i], self.channel_sizes[i + 1]))
+        self.att = mb.SelfAttention(self.channel_sizes[self.att_loc])
+
+    def forward(self, x):
+        for i in range(self.n_down_blocks):
+            if i == self.att_loc:
+                x = self.att(x)
+            x = self.down_blocks[i](x)
+        return ops.maxpool_lrelu(x)
+
+
+class EnvDecoder(nn.Module):
+    """models/gim_img_models.py:63-95.  forward: [N, style_dim] -> NHWC [N, S, S, C]."""
+
+    def __init__(self, img_size, img_channels, style_dim=512, min_n_channels=64):
+        super().__init__()
+        self.img_size, self.img_channels, self.style_dim = img_size, img_channels, style_dim
+        self.min_n_channels = min_n_channels
+        self.n_up_blocks = int(math.log2(img_size))
+        self.channel_sizes = list(
+            reversed([min(style_dim, int(self.min_n_channels * (2 ** i))) for i in range(self.n_up_blocks)])
+        ) + [img_channels]
+        self.att_loc = int(math.ceil(self.n_up_blocks / 2))
+        self.up_blocks = nn.ModuleList()
+        for i in range(self.n_up_blocks):
+            self.up_blocks.append(mb.ResBlockUp(self.channel_sizes[i], self.channel_sizes[i + 1]))
+        self.att = mb.SelfAttention(self.channel_sizes[self.att_loc])
+
+    def forward(self, x):
+        x = x.view(x.size(0), 1, 1, x.size(1))
+        for i in range(self.n_up_blocks):
+            if i == self.att_loc:
+                x = self.att(x)
+            x = self.up_blocks[i](x)
+        return x
+
+
+class Img2ImgDownModule(nn.Module):
+    """models/gim_img_models.py:101-139."""
+
+    def __init__(self, img_size, img_channels, style_dim=512, min_n_channels=64):
+        super().__init__()
+        self.img_size, self.img_channels, self.style_dim = img_size, img_channels, style_dim
+        self.n_down_blocks = int(math.log2(img_size)) - 2
+        self.min_n_channels = int(max(min_n_channels, style_dim / (2 ** (self.n_down_blocks - 1))))
+        self.channel_sizes = [img_channels] + [min(style_dim, int(self.min_n_channels * (2 ** i)))
+                                               for i in range(self.n_down_blocks)]
+        self.att_loc = int(math.ceil(self.n_down_blocks / 2))
+        self.down_blocks = nn.ModuleList()
+        self.in_layers = nn.ModuleList()
+        for i in range(self.n_down_blocks):
+            if i == 0:
+                self.down_blocks.append(mb.ResBlockDown(self.channel_sizes[i], self.channel_sizes[i + 1], conv_size=9, padding_size=4))
+            else:
+                self.down_blocks.append(mb.ResBlockDown(self.channel_sizes[i], self.channel_sizes[i + 1]))
+            self.in_layers.append(mb.GimInstanceNorm2d(self.channel_sizes[i + 1]))
+        self.att = mb.SelfAttention(self.channel_sizes[self.att_loc])
+
+    def forward(self, x):
+        for i in range(self.n_down_blocks):
+            if i == self.att_loc:
+                x = self.att(x)
+            x = self.down_blocks[i](x)
+            x = self.in_layers[i](x)
+        return x
+
+
+class Img2ImgAdaInResModule(nn.Module):
+    """models/gim_img_models.py:142-162."""
+
+    def __init__(self, style_dim=512, n_blocks=5):
+        super().__init__()
+        self.style_dim, self.n_blocks = style_dim, n_blocks
+        self.res_blocks = nn.ModuleList()
+        for _ in range(self.n_blocks):
+            self.res_blocks.append(mb.AdaResBlock2(channels=style_dim, style_dim=style_dim))
+
+    def forward(self, x, style):
+        for i in range(self.n_blocks):
+            x = self.res_blocks[i](x=x, style=style)
+        return x
+
+
+class Img2ImgAdaInUpModule(nn.Module):
+    """models/gim_img_models.py:165-215."""
+
+    def __init__(self, img_size, img_channels, style_dim=512, min_n_channels=64):
+        super().__init__()
+        self.img_size, self.img_channels, self.style_dim = img_size, img_channels, style_dim
+        self.n_up_blocks = int(math.log2(img_size)) - 2
+        self.min_n_channels = int(max(min_n_channels, style_dim / (2 ** (self.n_up_blocks - 1))))
+        self.channel_sizes = list(
+            reversed([min(style_dim, int(self.min_n_channels * (2 ** i))) for i in range(self.n_up_blocks)])
+        ) + [img_channels]
+        self.att_loc = int(math.ceil(self.n_up_blocks / 2))
+        self.up_blocks = nn.ModuleList()
+        for i in range(self.n_up_blocks):
+            if i == (self.n_up_blocks - 1):
+                self.up_blocks.append(mb.AdaResBlockUp2(in_channels=self.channel_sizes[i], out_channels=self.channel_sizes[i + 1],
+                                                        style_dim=style_dim, conv_size=9, padding_size=4))
+            else:
+                self.up_blocks.append(mb.AdaResBlockUp2(in_channels=self.channel_sizes[i], out_channels=self.channel_sizes[i + 1],
+                                                        style_dim=style_dim))
+        self.att = mb.SelfAttention(self.channel_sizes[self.att_loc])
+
+    def forward(self, x, style):
+        for i in range(self.n_up_blocks):
+            if i == self.att_loc:
+                x = self.att(x)
+            x = self.up_blocks[i](x=x, style=style)
+        return ops.tanh(x)
+
+
+class AdaInImage2Image(nn.Module):
+    """models/gim_img_models.py:218-257."""
+
+    def __init__(self, img_size, in_channels, out_channels, style_dim, n_adain_res_blocks=5, min_n_channels=64):
+        super().__init__()
+        self.img_size, self.in_channels, self.out_channels = img_size, in_channels, out_channels
+        self.style_dim, self.n_adain_res_blocks, self.min_n_channels = style_dim, n_adain_res_blocks, min_n_channels
+        self.down_block = Img2ImgDownModule(img_size=img_size, img_channels=in_channels, style_dim=style_dim,
+                                            min_n_channels=min_n_channels)
+        self.adain_res_block = Img2ImgAdaInResModule(style_dim=style_dim, n_blocks=n_adain_res_blocks)
+        self.adain_up_block = Img2ImgAdaInUpModule(img_size=img_size, img_channels=out_channels, style_dim=style_dim,
+                                                   min_n_channels=min_n_channels)
+
+    def forward(self, x, style):
+        x = self.down_block(x)
+        x = self.adain_res_block(x=x, style=style)
+        return self.adain_up_block(x=x, style=style)
+
+
+class GIMFaceDis(nn.Module):
+    """models/gim_img_models.py:263-299."""
+
+    def __init__(self, src_dim, env_dim, stat):
+        super().__init__()
+        self.src_dim, self.env_dim = src_dim, env_dim
+        self.stat = stat
+        self.n_stats = stat.n_stats
+        mlp_input_dim = 2 * (self.n_stats * env_dim + src_dim)
+        self.mlp = mb.MLP((mlp_input_dim, env_dim + src_dim, 2 * (env_dim + src_dim), 1))
+        # weights_init('kaiming') of the reference (models/model_blocks.py:18-38, applied at :277)
+        for m in self.mlp.model:
+            if isinstance(m, mb.GimLinear):
+                nn.init.kaiming_normal_(m.weight.data, a=0.2)
+                nn.init.constant_(m.bias.data, 0.0)
+
+    def forward(self, test_src, test_env, si_src, si_env):
+        fc_test = self.stat.fc.per_sample(test_env)
+        fc_si = self.stat.fc.per_sample(si_env)
+        x = ops.head_cat(test_src, test_env, si_src, si_env, fc_test, fc_si)
+        return self.mlp(x)
+
+
+def _encode_sample(encoder, sample):
+    """[B, t, C, S, S] (NCHW) -> [B, t, style_dim]."""
+    B, t = sample.size(0), sample.size(1)
+    x = ops.to_nhwc(sample.reshape(B * t, *sample.size()[2:]))
+    return encoder(x).view(B, t, -1)
+
+
+class GIMFaceAuthenticator(nn.Module):
+    """models/gim_img_models.py:304-340."""
+
+    def __init__(self, src_encoder, env_encoder, dis):
+        super().__init__()
+        self.src_encoder = src_encoder
+        self.env_encoder = env_encoder
+        self.dis = dis
+
+    def forward(self, test_sample, si_sample):
+        test_src = self.src_encode_sample(test_sample)
+        si_src = self.src_encode_sample(si_sample)
+        test_env = self.env_encode_sample(test_sample)
+        si_env = self.env_encode_sample(si_sample)
+        return self.dis(test_src=test_src, test_env=test_env, si_src=si_src, si_env=si_env)
+
+    def src_encode_sample(self, sample):
+        return _encode_sample(self.src_encoder, sample)
+
+    def env_encode_sample(self, sample):
+        return _encode_sample(self.env_encoder, sample)
+
+
+class GIMFaceImpersonator(nn.Module):
+    """models/gim_img_models.py:346-423."""
+
+    def __init__(self, src_encoder, env_encoder, env_decoder, img2img, env_noise_mapper, use_img_att=False):
+        super().__init__()
+        self.src_encoder = src_encoder
+        self.env_encoder = env_encoder
+        self.env_decoder = env_decoder
+        self.img2img = img2img
+        self.env_noise_mapper = env_noise_mapper
+        self.style_dim = src_encoder.style_dim
+        assert src_encoder.style_dim == env_encoder.style_dim == env_decoder.style_dim == img2img.style_dim
+        self.use_img_att = use_img_att
+        self.img_att = mb.ImgAttention(img1_channels=self.src_encoder.img_channels, img2_channels=self.img2img.out_channels)
+
+    def forward(self, leaked_sample, n, remove_noise_mean=True, z=None):
+        if self.use_img_att:
+            raise NotImplementedError("use_img_att=True is not on the accelerated hot path yet")
+        B, m, C, S, _ = leaked_sample.size()
+        leaked = ops.to_nhwc(leaked_sample.reshape(B * m, C, S, S))
+        src = ops.mean_dim1(self.src_encoder(leaked).view(B, m, -1))
+        env = ops.mean_dim1(self.env_encoder(leaked).view(B, m, -1))
+        if z is None:
+            z = torch.randn((B, n, self.style_dim), device=leaked_sample.device)
+        w = self.env_noise_mapper(z)
+        noisy_env = ops.noise_combine(env, w, remove_noise_mean)
+        env_img = self.env_decoder(noisy_env.view(B * n, -1))
+        first = leaked.view(B, m, S, S, C)[:, 0]
+        x = ops.concat2(env_img, first, n)
+        style = ops.repeat_dim1(src, n).view(B * n, self.style_dim)
+        out = self.img2img(x=x, style=style)
+        return ops.to_nchw(out).view(B, n, C, S, S)
+
+    def src_encode_sample(self, sample):
+        return _encode_sample(self.src_encoder, sample)
+
+    def env_encode_sample(self, sample):
+        return _encode_sample(self.env_encoder, sample)
+
+
+def get_im(img_size, img_channels, style_dim, use_img_att=False, num_env_noise_layers=4):
+    """models/gim_img_models.py:429-449."""
+    src_encoder = Encoder(img_size=img_size, img_channels=img_channels, style_dim=style_dim)
+    env_encoder = Encoder(img_size=img_size, img_channels=img_channels, style_dim=style_dim)
+    decoder = EnvDecoder(img_size=img_size, img_channels=img_channels, style_dim=style_dim)
+    img2img = AdaInImage2Image(img_size=img_size, in_channels=2 * img_channels, out_channels=img_channels, style_dim=style_dim)
+    env_noise_mapper = mb.MLP([style_dim for _ in range(num_env_noise_layers + 1)])
+    return GIMFaceImpersonator(src_encoder=src_encoder, env_encoder=env_encoder, env_decoder=decoder, img2img=img2img,
+                               env_noise_mapper=env_noise_mapper, use_img_att=use_img_att)
+
+
+def get_au(img_size, img_channels, style_dim):
+    """models/gim_img_models.py:452-463."""
+    stat = GIMMeanStdFcStat(style_dim=style_dim, fc_n_stats=2, fc_hidden_layers=(style_dim * 2, style_dim * 3, style_dim * 2))
+    dis = GIMFaceDis(src_dim=style_dim, env_dim=style_dim, stat=stat)
+    src_encoder = Encoder(img_size=img_size, img_channels=img_channels, style_dim=style_dim)
+    env_encoder = Encoder(img_size=img_size, img_channels=img_channels, style_dim=style_dim)
+    return GIMFaceAuthenticator(src_encoder=src_encoder, env_encoder=env_encoder, dis=dis)

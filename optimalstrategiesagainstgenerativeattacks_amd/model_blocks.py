@@ -1,0 +1,265 @@
+"""Building blocks of the GIM image agents on the MI355X engine.
+
+Host-side mirror of the used subset of the reference's ``models/model_blocks.py``: same class names,
+constructor arguments, sub-module / parameter names and registration order (so ``state_dict()`` keys,
+their order and ``parameters()`` order are those of the reference, incl. the spectral-norm
+``weight_orig`` / ``weight_u`` / ``weight_v`` triple), but every ``forward`` runs hand-written HIP
+kernels (``ops.py`` -> ``libgim_hip.so``) on NHWC activations, with the element-wise neighbours of each
+convolution fused into it:
+
+  LeakyReLU / nearest-upsample in front of a conv  -> conv prologue (gather)
+  1/sigma of spectral norm, bias, residual add     -> conv epilogue
+  avgpool(left) + avgpool(right)                   -> one avgpool of the summed branches (linearity)
+
+Unless noted, tensors between blocks are NHWC ``[N, H, W, C]`` float32 on the GPU.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+LRELU = 0.2
+
+
+def _kaiming_uniform_like_torch(weight, bias, fan_in):
+    """nn.Conv2d / nn.Linear default init (kaiming_uniform_(a=sqrt(5)); bias U(+-1/sqrt(fan_in)))."""
+    nn.init.kaiming_uniform_(weight, a=math.sqrt(5))
+    if bias is not None:
+        bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+        nn.init.uniform_(bias, -bound, bound)
+
+
+class GimLinear(nn.Module):
+    """nn.Linear (reference: models/model_blocks.py:86,89,786-789) with an optional fused LeakyReLU on its input."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        _kaiming_uniform_like_torch(self.weight, self.bias, in_features)
+
+    def forward(self, x, pre_slope=1.0):
+        return ops.linear(x, self.weight, self.bias, pre_slope)
+
+
+class FusedLeakyReLU(nn.Module):
+    """Placeholder keeping the reference's nn.Sequential indices (Linear at 0, 2, 4, ...): the activation
+    itself is applied in the prologue of the following linear kernel."""
+
+    def forward(self, x):  # pragma: no cover - never called, see MLP.forward
+        raise RuntimeError("FusedLeakyReLU is fused into the next GimLinear")
+
+
+class MLP(nn.Module):
+    """models/model_blocks.py:77-94."""
+
+    def __init__(self, layer_dims):
+        super().__init__()
+        assert len(layer_dims) >= 2
+        layers = []
+        inp_dim = layer_dims[0]
+        for out_dim in layer_dims[1:-1]:
+            layers.append(GimLinear(inp_dim, out_dim))
+            layers.append(FusedLeakyReLU())
+            inp_dim = out_dim
+        layers.append(GimLinear(inp_dim, layer_dims[-1]))
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        slope = 1.0
+        for layer in self.model:
+            if isinstance(layer, FusedLeakyReLU):
+                slope = LRELU
+            else:
+                x = layer(x, pre_slope=slope)
+                slope = 1.0
+        return x
+
+
+class SNConv2d(nn.Module):
+    """nn.utils.spectral_norm(nn.Conv2d(in, out, k, padding=(k-1)//2)) restated
+    (call sites models/model_blocks.py:492-495,522-526,744-750,792-793,836-840).
+
+    Parameters ``bias`` and ``weight_orig`` (logical [Cout, Cin, k, k], stored channels-last = the
+    [Cout][kh][kw][Cin] layout the kernels read), buffers ``weight_u`` / ``weight_v``.  Each call in
+    training mode does one power iteration in place (kernel), then the conv kernel applies 1/sigma in its
+    epilogue; backward differentiates through sigma w.r.t. ``weight_orig`` with u, v constant.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0):
+        super().__init__()
+        assert padding == (kernel_size - 1) // 2, "only 'same' stride-1 convolutions are on the GIM hot path"
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        w = torch.empty(out_channels, in_channels, kernel_size, kernel_size)
+        b = torch.empty(out_channels)
+        _kaiming_uniform_like_torch(w, b, in_channels * kernel_size * kernel_size)
+        # torch.nn.utils.spectral_norm.apply: u ~ N(0,1)[Cout], v ~ N(0,1)[Cin*k*k], both normalised
+        u = nn.functional.normalize(w.new_empty(out_channels).normal_(0, 1), dim=0, eps=1e-12)
+        v = nn.functional.normalize(w.new_empty(in_channels * kernel_size * kernel_size).normal_(0, 1), dim=0, eps=1e-12)
+        self.bias = nn.Parameter(b)
+        self.weight_orig = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        self.register_buffer("weight_u", u)
+        self.register_buffer("weight_v", v)
+
+    def forward(self, x, res=None, ups=0, pre_slope=1.0):
+        sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
+        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%d (spectral norm)" % (self.in_channels, self.out_channels, self.kernel_size)
+
+
+class GimInstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(C, affine=True) (models/gim_img_models.py:126, models/model_blocks.py:747-748)."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x):
+        return ops.instance_norm(x, self.weight, self.bias, self.eps)
+
+
+def custom_std(x):
+    """models/model_blocks.py:41-48 for x [B, t, D] (standalone helper; the head uses the fused HeadCatFn)."""
+    raise NotImplementedError("custom_std is fused into ops.head_cat on the hot path")
+
+
+class ResBlockDown(nn.Module):
+    """models/model_blocks.py:486-514.  avgpool(l) + avgpool(r) is computed as avgpool(l + r)."""
+
+    def __init__(self, in_channel, out_channel, conv_size=3, padding_size=1):
+        super().__init__()
+        self.conv_l1 = SNConv2d(in_channel, out_channel, 1)
+        self.conv_r1 = SNConv2d(in_channel, out_channel, conv_size, padding=padding_size)
+        self.conv_r2 = SNConv2d(out_channel, out_channel, conv_size, padding=padding_size)
+
+    def forward(self, x):
+        left = self.conv_l1(x)
+        out = self.conv_r1(x, pre_slope=LRELU)
+        out = self.conv_r2(out, res=left, pre_slope=LRELU)
+        return ops.avg_pool2(out)
+
+
+class SelfAttention(nn.Module):
+    """models/model_blocks.py:517-549."""
+
+    def __init__(self, in_channel):
+        super().__init__()
+        self.conv_f = SNConv2d(in_channel, in_channel // 8, 1)
+        self.conv_g = SNConv2d(in_channel, in_channel // 8, 1)
+        self.conv_h = SNConv2d(in_channel, in_channel, 1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        N, H, W, C = x.shape
+        f = self.conv_f(x).view(N, H * W, -1)
+        g = self.conv_g(x).view(N, H * W, -1)
+        h = self.conv_h(x).view(N, H * W, C)
+        out = ops.attn_core(f, g, h).view(N, H, W, C)
+        return ops.scale_add(out, x, self.gamma)
+
+
+class ImgAttConvBlock(nn.Module):
+    """models/model_blocks.py:551-578 (only reachable with use_img_att=True)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv_l1 = SNConv2d(in_channels, out_channels, 1)
+        self.conv_r1 = SNConv2d(in_channels, out_channels, 9, padding=4)
+        self.conv_r2 = SNConv2d(out_channels, out_channels, 3, padding=1)
+
+    def forward(self, x):
+        left = self.conv_l1(x)
+        out = self.conv_r1(x, pre_slope=LRELU)
+        return self.conv_r2(out, res=left, pre_slope=LRELU)
+
+
+class ImgAttention(nn.Module):
+    """models/model_blocks.py:581-608.  Parameters always exist (they are in the reference's state dict and
+    optimizer group); the forward is only reachable with use_img_att=True, which is outside the round-1
+    hot-path scope."""
+
+    def __init__(self, img1_channels, img2_channels):
+        super().__init__()
+        self.q1conv = ImgAttConvBlock(img1_channels + img2_channels, img1_channels)
+        self.q2conv = ImgAttConvBlock(img1_channels + img2_channels, img1_channels)
+        self.k1conv = ImgAttConvBlock(img1_channels, img1_channels)
+        self.k2conv = ImgAttConvBlock(img2_channels, img1_channels)
+        self.v2conv = ImgAttConvBlock(img2_channels, img1_channels)
+
+    def forward(self, x1, x2):
+        raise NotImplementedError("use_img_att=True is not on the accelerated hot path yet")
+
+
+class ResBlockUp(nn.Module):
+    """models/model_blocks.py:733-773."""
+
+    def __init__(self, in_channel, out_channel, out_size=None, scale=2, conv_size=3, padding_size=1, use_norm=True):
+        super().__init__()
+        assert out_size is None and scale == 2
+        self.in_channel, self.out_channel = in_channel, out_channel
+        self.conv_l1 = SNConv2d(in_channel, out_channel, 1)
+        self.in1 = GimInstanceNorm2d(in_channel)
+        self.in2 = GimInstanceNorm2d(out_channel)
+        self.conv_r1 = SNConv2d(in_channel, out_channel, conv_size, padding=padding_size)
+        self.conv_r2 = SNConv2d(out_channel, out_channel, conv_size, padding=padding_size)
+
+    def forward(self, x):
+        left = self.conv_l1(x, ups=1)
+        out = self.in1(x)
+        out = self.conv_r1(out, ups=1, pre_slope=LRELU)
+        out = self.in2(out)
+        return self.conv_r2(out, res=left, pre_slope=LRELU)
+
+
+class AdaResBlock2(nn.Module):
+    """models/model_blocks.py:776-814.  ``style`` is [N, style_dim]."""
+
+    def __init__(self, channels, style_dim):
+        super().__init__()
+        self.style_dim, self.channels = style_dim, channels
+        self.lin1_mean = GimLinear(style_dim, channels)
+        self.lin1_std = GimLinear(style_dim, channels)
+        self.lin2_mean = GimLinear(style_dim, channels)
+        self.lin2_std = GimLinear(style_dim, channels)
+        self.conv1 = SNConv2d(channels, channels, 3, padding=1)
+        self.conv2 = SNConv2d(channels, channels, 3, padding=1)
+
+    def forward(self, x, style):
+        m1, s1 = self.lin1_mean(style), self.lin1_std(style)
+        m2, s2 = self.lin2_mean(style), self.lin2_std(style)
+        out = self.conv1(x)
+        out = ops.ada_in(out, m1, s1)
+        out = self.conv2(out, pre_slope=LRELU)
+        return ops.ada_in(out, m2, s2, res=x)
+
+
+class AdaResBlockUp2(nn.Module):
+    """models/model_blocks.py:817-865."""
+
+    def __init__(self, in_channels, out_channels, style_dim, out_size=None, scale=2, conv_size=3, padding_size=1):
+        super().__init__()
+        assert out_size is None and scale == 2
+        self.in_channels, self.out_channels, self.style_dim = in_channels, out_channels, style_dim
+        self.lin1_mean = GimLinear(style_dim, in_channels)
+        self.lin1_std = GimLinear(style_dim, in_channels)
+        self.lin2_mean = GimLinear(style_dim, out_channels)
+        self.lin2_std = GimLinear(style_dim, out_channels)
+        self.conv_l1 = SNConv2d(in_channels, out_channels, 1)
+        self.conv_r1 = SNConv2d(in_channels, out_channels, conv_size, padding=padding_size)
+        self.conv_r2 = SNConv2d(out_channels, out_channels, conv_size, padding=padding_size)
+
+    def forward(self, x, style):
+        m1, s1 = self.lin1_mean(style), self.lin1_std(style)
+        m2, s2 = self.lin2_mean(style), self.lin2_std(style)
+        left = self.conv_l1(x, ups=1)
+        out = ops.ada_in(x, m1, s1)
+        out = self.conv_r1(out, ups=1, pre_slope=LRELU)
+        out = ops.ada_in(out, m2, s2)
+        return self.conv_r2(out, res=left, pre_slope=LRELU)

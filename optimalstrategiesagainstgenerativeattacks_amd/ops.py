@@ -1,0 +1,602 @@
+"""Autograd operators over the C ABI of libgim_hip.so (include/gim_hip.h).
+
+Every operator here launches hand-written HIP kernels on torch's current stream through ctypes;
+torch supplies device memory, streams and the autograd tape only.  There is no CPU path: tensors
+must be CUDA(HIP) float32.  Activations are NHWC.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import GimConvShape, check
+
+LRELU_SLOPE = 0.2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, off=0):
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * off
+
+
+def _req(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError("%s must be a CUDA float32 tensor (got %s on %s): the GIM engine has no CPU path"
+                           % (name, t.dtype, t.device))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def weight_phys(w):
+    """The [Cout][KH][KW][Cin] storage view of a conv weight parameter (logical [Cout,Cin,KH,KW] kept
+    channels-last), or the [out][in] linear weight itself."""
+    if w.dim() == 2:
+        return w if w.is_contiguous() else w.contiguous()
+    wp = w.permute(0, 2, 3, 1)
+    return wp if wp.is_contiguous() else wp.contiguous()
+
+
+def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope):
+    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope)
+
+
+# --------------------------------------------------------------------------------------------
+# spectral norm power iteration (no autograd: u, v are constants for the gradient, see ConvFn.backward)
+# --------------------------------------------------------------------------------------------
+@torch.no_grad()
+def spectral_sigma(w, u, v, training):
+    """torch.nn.utils.spectral_norm semantics; returns (sigma[1], u_used[Cout], v_used[K])."""
+    lib = _lib.load()
+    wp = weight_phys(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    KH = w.shape[2] if w.dim() == 4 else 1
+    K = Cin * KH * KH
+    sigma = torch.empty(1, device=w.device, dtype=torch.float32)
+    u_s = torch.empty_like(u)
+    v_s = torch.empty_like(v)
+    scratch = torch.empty(9 * K + Cout, device=w.device, dtype=torch.float32)
+    check(lib.gim_spectral_sigma(_p(wp), _p(u), _p(v), _p(sigma), _p(u_s), _p(v_s), _p(scratch), Cout, Cin, KH,
+                                 1 if training else 0, _stream()), "spectral_sigma")
+    return sigma, u_s, v_s
+
+
+# --------------------------------------------------------------------------------------------
+# convolution / linear
+# --------------------------------------------------------------------------------------------
+class ConvFn(Function):
+    """y = conv(up2^ups(lrelu(x, pre_slope)), w) / sigma + bias + res   (NHWC; linear when x is 2-D)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope):
+        lib = _lib.load()
+        x = _req(x, "x")
+        wp = weight_phys(_req_w(w))
+        if x.dim() == 2:
+            N, Hs, Ws, Cin = x.shape[0], 1, 1, x.shape[1]
+        else:
+            N, Hs, Ws, Cin = x.shape
+        Cout = w.shape[0]
+        KH = w.shape[2] if w.dim() == 4 else 1
+        if w.shape[1] != Cin:
+            raise RuntimeError("conv: weight expects %d input channels, got %d" % (w.shape[1], Cin))
+        H, W = Hs << ups, Ws << ups
+        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope)
+        y = torch.empty((N, Cout) if x.dim() == 2 else (N, H, W, Cout), device=x.device, dtype=torch.float32)
+        if res is not None:
+            res = _req(res, "res")
+        check(lib.gim_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd")
+        ctx.save_for_backward(x, w, sigma, u_s, v_s)
+        ctx.cfg = (N, H, W, Cin, Cout, KH, ups, pre_slope, bias is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, sigma, u_s, v_s = ctx.saved_tensors
+        N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res = ctx.cfg
+        dy = _req(dy, "dy")
+        wp = weight_phys(w)
+        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope)
+        st = _stream()
+        dev = dy.device
+        dx = dw = db = dres = None
+        mask = x if pre_slope != 1.0 else None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if ups:
+                dxu = torch.empty((N, H, W, Cin), device=dev, dtype=torch.float32)
+                check(lib.gim_conv2d_dgrad(_p(dy), _p(wp), _p(sigma), None, _p(dxu), sh, st), "conv2d_dgrad")
+                check(lib.gim_upsample2x_bwd(_p(dxu), _p(mask), pre_slope, _p(dx), N, H >> 1, W >> 1, Cin, st), "upsample2x_bwd")
+            else:
+                check(lib.gim_conv2d_dgrad(_p(dy), _p(wp), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            ns = lib.gim_conv2d_wgrad_slabs(sh)
+            if ns <= 0:
+                check(ns, "conv2d_wgrad_slabs")
+            K = KH * KH * Cin
+            dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
+            if ns == 1 and sigma is None:
+                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(dwp), 1, sh, st), "conv2d_wgrad")
+            else:
+                slabs = torch.empty(ns * Cout * K, device=dev, dtype=torch.float32)
+                scratch = torch.empty(512, device=dev, dtype=torch.float32)
+                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(slabs), ns, sh, st), "conv2d_wgrad")
+                check(lib.gim_wgrad_finish(_p(slabs), ns, _p(wp), _p(sigma), _p(u_s), _p(v_s), _p(dwp), _p(scratch),
+                                           Cout, Cin, KH, st), "wgrad_finish")
+            dw = dwp.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2) if w.dim() == 4 else dwp.view(Cout, Cin)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, device=dev, dtype=torch.float32)
+            scratch = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
+            check(lib.gim_colsum(_p(dy), _p(db), _p(scratch), N * H * W, Cout, st), "colsum")
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None, None, None, None, None
+
+
+def _req_w(w):
+    if not (w.is_cuda and w.dtype == torch.float32):
+        raise RuntimeError("weights must be CUDA float32 (got %s on %s): the GIM engine has no CPU path" % (w.dtype, w.device))
+    return w
+
+
+def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0):
+    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope)
+
+
+def linear(x, w, bias=None, pre_slope=1.0):
+    """nn.Linear on the last dim (optionally with a fused LeakyReLU on the input)."""
+    shp = x.shape
+    y = ConvFn.apply(x.reshape(-1, shp[-1]), w, bias, None, None, None, None, 0, pre_slope)
+    return y.view(*shp[:-1], w.shape[0])
+
+
+# --------------------------------------------------------------------------------------------
+# instance norm / AdaIN
+# --------------------------------------------------------------------------------------------
+class NormFn(Function):
+    """mode 0: InstanceNorm2d(affine) with scale/shift [C]; mode 1: ada_in with scale/shift [N,C].
+    Optional residual added to the output.  x NHWC [N,H,W,C]."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, res, mode, eps):
+        lib = _lib.load()
+        x = _req(x, "x")
+        scale = _req(scale, "scale")
+        shift = _req(shift, "shift")
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((N, C, 3), device=x.device, dtype=torch.float32)
+        if res is not None:
+            res = _req(res, "res")
+        check(lib.gim_norm_fwd(_p(x), _p(scale), _p(shift), _p(res), _p(y), _p(stats), N, H * W, C, mode, eps, _stream()), "norm_fwd")
+        ctx.save_for_backward(x, scale, stats)
+        ctx.cfg = (N, H * W, C, mode, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, scale, stats = ctx.saved_tensors
+        N, HW, C, mode, has_res = ctx.cfg
+        dy = _req(dy, "dy")
+        st = _stream()
+        dx = torch.empty_like(x)
+        dsc = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        dsh = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        check(lib.gim_norm_bwd(_p(dy), _p(x), _p(scale), _p(stats), _p(dx), _p(dsc), _p(dsh), N, HW, C, mode, st), "norm_bwd")
+        if mode == 0:
+            dscale = torch.empty(C, device=x.device, dtype=torch.float32)
+            dshift = torch.empty(C, device=x.device, dtype=torch.float32)
+            scratch = torch.empty(256 * C, device=x.device, dtype=torch.float32)
+            check(lib.gim_colsum(_p(dsc), _p(dscale), _p(scratch), N, C, st), "colsum")
+            check(lib.gim_colsum(_p(dsh), _p(dshift), _p(scratch), N, C, st), "colsum")
+        else:
+            dscale, dshift = dsc.view_as(scale), dsh.view_as(scale)
+        return dx, dscale, dshift, (dy if has_res else None), None, None
+
+
+def instance_norm(x, weight, bias, eps=1e-5):
+    return NormFn.apply(x, weight, bias, None, 0, eps)
+
+
+def ada_in(x, mean_style, std_style, res=None, eps=1e-5):
+    return NormFn.apply(x, std_style, mean_style, res, 1, eps)
+
+
+# --------------------------------------------------------------------------------------------
+# pooling / pointwise
+# --------------------------------------------------------------------------------------------
+class AvgPool2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _req(x, "x")
+        N, H, W, C = x.shape
+        y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
+        check(lib.gim_avgpool2_fwd(_p(x), _p(y), N, H, W, C, _stream()), "avgpool2_fwd")
+        ctx.cfg = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, H, W, C = ctx.cfg
+        dy = _req(dy, "dy")
+        dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
+        check(lib.gim_avgpool2_bwd(_p(dy), _p(dx), N, H, W, C, _stream()), "avgpool2_bwd")
+        return dx
+
+
+class MaxPoolLreluFn(Function):
+    """AdaptiveMaxPool2d((1,1)) -> flatten -> LeakyReLU(0.2) on NHWC input; output [N, C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _req(x, "x")
+        N, H, W, C = x.shape
+        y = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, C), device=x.device, dtype=torch.int32)
+        check(lib.gim_maxpool_lrelu_fwd(_p(x), _p(y), idx.data_ptr(), N, H * W, C, LRELU_SLOPE, _stream()), "maxpool_lrelu_fwd")
+        ctx.save_for_backward(y, idx)
+        ctx.cfg = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        y, idx = ctx.saved_tensors
+        N, H, W, C = ctx.cfg
+        dy = _req(dy, "dy")
+        dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
+        check(lib.gim_maxpool_lrelu_bwd(_p(dy), _p(y), idx.data_ptr(), _p(dx), N, H * W, C, LRELU_SLOPE, _stream()), "maxpool_lrelu_bwd")
+        return dx
+
+
+class TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _req(x, "x")
+        y = torch.empty_like(x)
+        check(lib.gim_tanh_fwd(_p(x), _p(y), x.numel(), _stream()), "tanh_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        dx = torch.empty_like(y)
+        check(lib.gim_tanh_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream()), "tanh_bwd")
+        return dx
+
+
+class ScaleAddFn(Function):
+    """y = gamma * a + x with gamma a 1-element parameter (SelfAttention output)."""
+
+    @staticmethod
+    def forward(ctx, a, x, gamma):
+        lib = _lib.load()
+        a, x = _req(a, "a"), _req(x, "x")
+        y = torch.empty_like(x)
+        check(lib.gim_scale_add_fwd(_p(a), _p(x), _p(gamma), _p(y), x.numel(), _stream()), "scale_add_fwd")
+        ctx.save_for_backward(a, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        a, gamma = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        da = torch.empty_like(a)
+        dg = torch.empty(1, device=dy.device, dtype=torch.float32)
+        scratch = torch.empty(2048, device=dy.device, dtype=torch.float32)
+        check(lib.gim_scale_add_bwd(_p(dy), _p(a), _p(gamma), _p(da), _p(dg), _p(scratch), a.numel(), _stream()), "scale_add_bwd")
+        return da, dy, dg.view_as(gamma)
+
+
+class ToNHWCFn(Function):
+    """[N, C, H, W] contiguous -> [N, H, W, C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _req(x, "x")
+        N, C, H, W = x.shape
+        ctx.cfg = (N, C, H, W)
+        if C == 1:
+            return x.view(N, H, W, 1)
+        y = torch.empty((N, H, W, C), device=x.device, dtype=torch.float32)
+        check(lib.gim_nchw_to_nhwc(_p(x), _p(y), N, C, H * W, _stream()), "nchw_to_nhwc")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, C, H, W = ctx.cfg
+        dy = _req(dy, "dy")
+        if C == 1:
+            return dy.view(N, 1, H, W)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        check(lib.gim_nhwc_to_nchw(_p(dy), _p(dx), N, C, H * W, _stream()), "nhwc_to_nchw")
+        return dx
+
+
+class ToNCHWFn(Function):
+    """[N, H, W, C] contiguous -> [N, C, H, W]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _req(x, "x")
+        N, H, W, C = x.shape
+        ctx.cfg = (N, C, H, W)
+        if C == 1:
+            return x.view(N, 1, H, W)
+        y = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+        check(lib.gim_nhwc_to_nchw(_p(x), _p(y), N, C, H * W, _stream()), "nhwc_to_nchw")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, C, H, W = ctx.cfg
+        dy = _req(dy, "dy")
+        if C == 1:
+            return dy.view(N, H, W, 1)
+        dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
+        check(lib.gim_nchw_to_nhwc(_p(dy), _p(dx), N, C, H * W, _stream()), "nchw_to_nhwc")
+        return dx
+
+
+# --------------------------------------------------------------------------------------------
+# self-attention core
+# --------------------------------------------------------------------------------------------
+def _bgemm(A, B, C, batch, M, N, K, sA, sB):
+    check(_lib.load().gim_bgemm(_p(A), _p(B), _p(C), batch, M, N, K, sA[0], sA[1], sA[2], sB[0], sB[1], sB[2], _stream()), "bgemm")
+
+
+class AttnCoreFn(Function):
+    """out[b, j, :] = sum_i softmax_i(f[b,i,:] . g[b,j,:]) * h[b,i,:]   (tokens = pixels, NHWC rows)."""
+
+    @staticmethod
+    def forward(ctx, f, g, h):
+        lib = _lib.load()
+        f, g, h = _req(f, "f"), _req(g, "g"), _req(h, "h")
+        Nb, P, Cq = f.shape
+        C = h.shape[2]
+        dev = f.device
+        S = torch.empty((Nb, P, P), device=dev, dtype=torch.float32)
+        _bgemm(f, g, S, Nb, P, P, Cq, (P * Cq, Cq, 1), (P * Cq, 1, Cq))
+        A = torch.empty_like(S)
+        check(lib.gim_softmax_dim1_fwd(_p(S), _p(A), Nb, P, P, _stream()), "softmax_dim1_fwd")
+        out = torch.empty((Nb, P, C), device=dev, dtype=torch.float32)
+        _bgemm(A, h, out, Nb, P, C, P, (P * P, 1, P), (P * C, C, 1))
+        ctx.save_for_backward(f, g, h, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        f, g, h, A = ctx.saved_tensors
+        dout = _req(dout, "dout")
+        Nb, P, Cq = f.shape
+        C = h.shape[2]
+        dev = f.device
+        dh = torch.empty_like(h)
+        _bgemm(A, dout, dh, Nb, P, C, P, (P * P, P, 1), (P * C, C, 1))
+        dA = torch.empty_like(A)
+        _bgemm(h, dout, dA, Nb, P, P, C, (P * C, C, 1), (P * C, 1, C))
+        dS = torch.empty_like(A)
+        check(lib.gim_softmax_dim1_bwd(_p(dA), _p(A), _p(dS), Nb, P, P, _stream()), "softmax_dim1_bwd")
+        df = torch.empty_like(f)
+        _bgemm(dS, g, df, Nb, P, Cq, P, (P * P, P, 1), (P * Cq, Cq, 1))
+        dg = torch.empty_like(g)
+        _bgemm(dS, f, dg, Nb, P, Cq, P, (P * P, 1, P), (P * Cq, Cq, 1))
+        return df, dg, dh
+
+
+# --------------------------------------------------------------------------------------------
+# set pooling (authenticator head) and small glue of the generator
+# --------------------------------------------------------------------------------------------
+class SumDim1Fn(Function):
+    """y[b] = scale * sum_j x[b, j]  for x [B, t, D]."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        lib = _lib.load()
+        x = _req(x, "x")
+        B, t, D = x.shape
+        y = torch.empty((B, D), device=x.device, dtype=torch.float32)
+        check(lib.gim_sum_dim1(_p(x), _p(y), B, t, D, scale, _stream()), "sum_dim1")
+        ctx.cfg = (B, t, D, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, t, D, scale = ctx.cfg
+        dy = _req(dy, "dy")
+        dx = torch.empty((B, t, D), device=dy.device, dtype=torch.float32)
+        check(lib.gim_repeat_dim1(_p(dy), _p(dx), B, t, D, scale, _stream()), "repeat_dim1")
+        return dx, None
+
+
+class RepeatDim1Fn(Function):
+    """y[b, j] = x[b] for j < t: [B, D] -> [B, t, D]."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        lib = _lib.load()
+        x = _req(x, "x")
+        B, D = x.shape
+        y = torch.empty((B, t, D), device=x.device, dtype=torch.float32)
+        check(lib.gim_repeat_dim1(_p(x), _p(y), B, t, D, 1.0, _stream()), "repeat_dim1")
+        ctx.cfg = (B, t, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, t, D = ctx.cfg
+        dy = _req(dy, "dy")
+        dx = torch.empty((B, D), device=dy.device, dtype=torch.float32)
+        check(lib.gim_sum_dim1(_p(dy), _p(dx), B, t, D, 1.0, _stream()), "sum_dim1")
+        return dx, None
+
+
+def mean_dim1(x):
+    return SumDim1Fn.apply(x, 1.0 / x.shape[1])
+
+
+class NoiseCombineFn(Function):
+    """noisy[b, j] = env[b] + w[b, j] - mean_j w[b, j]  (mean term iff remove_mean)."""
+
+    @staticmethod
+    def forward(ctx, env, w, remove_mean):
+        lib = _lib.load()
+        env, w = _req(env, "env"), _req(w, "w")
+        B, t, D = w.shape
+        y = torch.empty_like(w)
+        check(lib.gim_noise_combine(_p(env), _p(w), _p(y), B, t, D, 1 if remove_mean else 0, _stream()), "noise_combine")
+        ctx.cfg = (B, t, D, remove_mean)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, t, D, remove_mean = ctx.cfg
+        dy = _req(dy, "dy")
+        denv = torch.empty((B, D), device=dy.device, dtype=torch.float32)
+        check(lib.gim_sum_dim1(_p(dy), _p(denv), B, t, D, 1.0, _stream()), "sum_dim1")
+        dw = torch.empty_like(dy)
+        check(lib.gim_noise_combine(None, _p(dy), _p(dw), B, t, D, 1 if remove_mean else 0, _stream()), "noise_combine")
+        return denv, dw, None
+
+
+class Concat2Fn(Function):
+    """cat((a, b broadcast), channel) for NHWC a [R_img, H, W, Ca] and b [R_img/rep, H, W, Cb]
+    (each b image serves `rep` consecutive a images).  Gradient flows to a only."""
+
+    @staticmethod
+    def forward(ctx, a, b, rep):
+        lib = _lib.load()
+        a, b = _req(a, "a"), _req(b, "b")
+        Ni, H, W, Ca = a.shape
+        Cb = b.shape[3]
+        y = torch.empty((Ni, H, W, Ca + Cb), device=a.device, dtype=torch.float32)
+        check(lib.gim_concat2(_p(a), _p(b), _p(y), Ni * H * W, Ca, Cb, H * W, rep, _stream()), "concat2")
+        ctx.cfg = (Ni, H, W, Ca, Cb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        Ni, H, W, Ca, Cb = ctx.cfg
+        dy = _req(dy, "dy")
+        da = torch.empty((Ni, H, W, Ca), device=dy.device, dtype=torch.float32)
+        check(lib.gim_slice_channels(_p(dy), _p(da), Ni * H * W, Ca, Ca + Cb, _stream()), "slice_channels")
+        return da, None, None
+
+
+class HeadCatFn(Function):
+    """The [B, 2*(Ds + 2*De + Df)] input of the authenticator's MLP:
+    cat(mean(test_src), mean(si_src), [mean, custom_std](test_env), mean(fc_test), [mean, custom_std](si_env), mean(fc_si))
+    where fc_* are the per-sample outputs of the FC-stat MLP."""
+
+    @staticmethod
+    def forward(ctx, test_src, test_env, si_src, si_env, fc_test, fc_si):
+        lib = _lib.load()
+        ts, te, ss, se, ft, fs = [_req(t, "head input") for t in (test_src, test_env, si_src, si_env, fc_test, fc_si)]
+        B, n, Ds = ts.shape
+        k = ss.shape[1]
+        De, Df = te.shape[2], ft.shape[2]
+        L = 2 * (Ds + 2 * De + Df)
+        out = torch.empty((B, L), device=ts.device, dtype=torch.float32)
+        st = _stream()
+        o_te = 2 * Ds
+        o_se = o_te + 2 * De + Df
+        check(lib.gim_set_stats_fwd(_p(ts), _p(out, 0), None, B, n, Ds, L, L, st), "set_stats_fwd")
+        check(lib.gim_set_stats_fwd(_p(ss), _p(out, Ds), None, B, k, Ds, L, L, st), "set_stats_fwd")
+        check(lib.gim_set_stats_fwd(_p(te), _p(out, o_te), _p(out, o_te + De), B, n, De, L, L, st), "set_stats_fwd")
+        check(lib.gim_set_stats_fwd(_p(ft), _p(out, o_te + 2 * De), None, B, n, Df, L, L, st), "set_stats_fwd")
+        check(lib.gim_set_stats_fwd(_p(se), _p(out, o_se), _p(out, o_se + De), B, k, De, L, L, st), "set_stats_fwd")
+        check(lib.gim_set_stats_fwd(_p(fs), _p(out, o_se + 2 * De), None, B, k, Df, L, L, st), "set_stats_fwd")
+        ctx.save_for_backward(ts, te, ss, se, ft, fs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        ts, te, ss, se, ft, fs = ctx.saved_tensors
+        dout = _req(dout, "dout")
+        B, n, Ds = ts.shape
+        k = ss.shape[1]
+        De, Df = te.shape[2], ft.shape[2]
+        L = dout.shape[1]
+        st = _stream()
+        o_te = 2 * Ds
+        o_se = o_te + 2 * De + Df
+        need = ctx.needs_input_grad
+        grads = [None] * 6
+
+        def bwd(i, x, t, D, o_mean, o_std):
+            if not need[i]:
+                return
+            dx = torch.empty_like(x)
+            check(lib.gim_set_stats_bwd(_p(x), _p(dout, o_mean), (_p(dout, o_std) if o_std is not None else None), _p(dx),
+                                        B, t, D, L, L, st), "set_stats_bwd")
+            grads[i] = dx
+
+        bwd(0, ts, n, Ds, 0, None)
+        bwd(1, te, n, De, o_te, o_te + De)
+        bwd(2, ss, k, Ds, Ds, None)
+        bwd(3, se, k, De, o_se, o_se + De)
+        bwd(4, ft, n, Df, o_te + 2 * De, None)
+        bwd(5, fs, k, Df, o_se + 2 * De, None)
+        return tuple(grads)
+
+
+class BCELogitsFn(Function):
+    """binary_cross_entropy_with_logits(x, full_like(x, target), reduction='none')."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        lib = _lib.load()
+        x = _req(x, "x")
+        loss = torch.empty_like(x)
+        check(lib.gim_bce_logits_fwd(_p(x), _p(loss), target, x.numel(), _stream()), "bce_logits_fwd")
+        ctx.save_for_backward(x)
+        ctx.target = target
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dl = _req(dl, "dloss")
+        dx = torch.empty_like(x)
+        check(lib.gim_bce_logits_bwd(_p(dl), _p(x), _p(dx), ctx.target, x.numel(), _stream()), "bce_logits_bwd")
+        return dx, None
+
+
+avg_pool2 = AvgPool2Fn.apply
+maxpool_lrelu = MaxPoolLreluFn.apply
+tanh = TanhFn.apply
+scale_add = ScaleAddFn.apply
+to_nhwc = ToNHWCFn.apply
+to_nchw = ToNCHWFn.apply
+attn_core = AttnCoreFn.apply
+noise_combine = NoiseCombineFn.apply
+concat2 = Concat2Fn.apply
+head_cat = HeadCatFn.apply
+bce_logits = BCELogitsFn.apply
+
+
+def repeat_dim1(x, t):
+    return RepeatDim1Fn.apply(x, t)

@@ -1,0 +1,116 @@
+"""Small host-side pieces of the reference's ``training/utils.py`` / ``training/checkpoints.py`` that the
+trainer protocol needs (GlobalStep :15-33, DataParallelMock :36-42, adjust_batch_size :167-171,
+CheckpointIO training/checkpoints.py:9-44), plus ``EpisodeParallel``: the one-process-per-GPU replacement of
+``nn.DataParallel`` (training/gim_img_training.py:406-411)."""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class GlobalStep(object):
+    def __init__(self, gs=-1):
+        self._gs = gs
+
+    def step(self):
+        self._gs += 1
+
+    def get(self):
+        return self._gs
+
+    def set(self, gs):
+        self._gs = gs
+
+    def state_dict(self):
+        return {"global_step": self._gs}
+
+    def load_state_dict(self, d):
+        self.set(d["global_step"])
+
+
+class DataParallelMock:
+    """Gives a bare trainer the ``.module`` attribute the training loop addresses."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def forward(self, *inputs, **kwargs):
+        return self.module.forward(*inputs, **kwargs)
+
+
+class EpisodeParallel(DataParallelMock):
+    """Data parallelism over episodes, MI355X style: one process per GPU, both agents and both Adam states
+    replicated, the episode batch sharded across ranks by the caller (``shard``), and ONE RCCL all-reduce of
+    each optimizer's flat gradient bucket per step (done inside ``FusedAdam.step``).  Spectral-norm u/v need no
+    synchronisation (data independent); the latent noise z is drawn per rank.  Same ``.module`` /
+    ``.forward(mode=...)`` surface as ``nn.DataParallel`` has in the reference loop."""
+
+    def __init__(self, module):
+        super().__init__(module)
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+
+    def shard(self, *tensors):
+        """The local slice (dim 0 = episodes) of globally batched tensors; batch % world_size must be 0
+        (the reference asserts the same, training/utils.py:167-171)."""
+        out = []
+        for t in tensors:
+            assert t.size(0) % self.world_size == 0, "episode batch must be divisible by the number of GPUs"
+            per = t.size(0) // self.world_size
+            out.append(t[self.rank * per:(self.rank + 1) * per])
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def broadcast_parameters(self):
+        """Make every rank start from rank 0's parameters and buffers."""
+        if self.world_size > 1:
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t.data, src=0)
+
+
+def adjust_batch_size(ds_length, curr_batch_size, n_devices):
+    batch_size = min(curr_batch_size, ds_length)
+    batch_size = int(n_devices * math.floor(batch_size / n_devices))
+    assert batch_size % n_devices == 0 and batch_size > 0
+    return batch_size
+
+
+def num_parameters(parameter_list):
+    return float(sum(p.numel() for p in parameter_list))
+
+
+class CheckpointIO:
+    """training/checkpoints.py:9-44: one ``torch.save`` dict {global_step, last_epoch, <name>: state_dict...};
+    the int 'global_step' entry is overwritten by the registered GlobalStep's state dict, as in the reference."""
+
+    def __init__(self, checkpoint_dir, **kwargs):
+        self.module_dict = kwargs
+        self.checkpoint_dir = checkpoint_dir
+        if not os.path.exists(checkpoint_dir):
+            os.makedirs(checkpoint_dir)
+
+    def register_modules(self, **kwargs):
+        self.module_dict.update(kwargs)
+
+    def save(self, global_step, last_epoch, filename):
+        filename = os.path.join(self.checkpoint_dir, filename)
+        outdict = {"global_step": global_step, "last_epoch": last_epoch}
+        for k, v in self.module_dict.items():
+            outdict[k] = v.state_dict()
+        torch.save(outdict, filename)
+
+    def load(self, filepath):
+        if os.path.exists(filepath):
+            print("=> Loading checkpoint...")
+            out_dict = torch.load(filepath, map_location="cpu", weights_only=False)
+            global_step = out_dict["global_step"]
+            last_epoch = out_dict["last_epoch"]
+            for k, v in self.module_dict.items():
+                if k in out_dict:
+                    v.load_state_dict(out_dict[k])
+                else:
+                    print("Warning: Could not find %s in checkpoint!" % k)
+        else:
+            global_step = -1
+            last_epoch = -1
+        return global_step, last_epoch

@@ -1,0 +1,227 @@
+"""GPU parity, block / network / trainer level: the product modules (HIP path through the C ABI) against the
+golden vectors captured from the reference (tests/golden, fp64) and against the oracle on the same seeded
+inputs.  north_star tolerance: 1e-3 relative on losses / logits (stated per assert)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gim_oracle as go
+from oracle import portable_fill as pf
+from tests.helpers import T, episode, filled_sd, load_json, load_keys, load_npz, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def nhwc(x):
+    return x.detach().permute(0, 2, 3, 1).contiguous().float().to(dev())
+
+
+def nchw(y):
+    return y.detach().permute(0, 3, 1, 2).double().cpu()
+
+
+def fill_module(mod, tag):
+    sd = filled_sd([(k, tuple(v.shape)) for k, v in mod.state_dict().items()], tag, torch.float32)
+    mod.load_state_dict(sd)
+    return mod.to(dev())
+
+
+def _blocks():
+    from optimalstrategiesagainstgenerativeattacks_amd import model_blocks as mb
+    return {
+        "resdown3": (lambda: mb.ResBlockDown(4, 8), dict(x=(2, 4, 8, 8)), ("x",)),
+        "resdown9": (lambda: mb.ResBlockDown(3, 8, conv_size=9, padding_size=4), dict(x=(2, 3, 16, 16)), ("x",)),
+        "resup": (lambda: mb.ResBlockUp(8, 4), dict(x=(2, 8, 4, 4)), ("x",)),
+        "resup1x1": (lambda: mb.ResBlockUp(8, 4), dict(x=(3, 8, 1, 1)), ("x",)),
+        "adares": (lambda: mb.AdaResBlock2(8, 6), dict(x=(2, 8, 4, 4), style=(2, 6)), ("x", "style")),
+        "adaresup3": (lambda: mb.AdaResBlockUp2(8, 4, 6), dict(x=(2, 8, 4, 4), style=(2, 6)), ("x", "style")),
+        "adaresup9": (lambda: mb.AdaResBlockUp2(8, 3, 6, conv_size=9, padding_size=4), dict(x=(2, 8, 8, 8), style=(2, 6)), ("x", "style")),
+        "selfatt": (lambda: mb.SelfAttention(16), dict(x=(2, 16, 4, 4)), ("x",)),
+        "mlp": (lambda: mb.MLP((6, 10, 12, 4)), dict(x=(5, 6)), ("x",)),
+    }
+
+
+@pytest.mark.parametrize("name", ["resdown3", "resdown9", "resup", "resup1x1", "adares", "adaresup3", "adaresup9", "selfatt", "mlp"])
+def test_block_vs_reference_golden(name):
+    """Same named weights / inputs as oracle/make_golden.py fed to the reference block (fp64)."""
+    g = load_npz("blocks.npz")
+    ctor, inputs, order = _blocks()[name]
+    mod = fill_module(ctor(), name + "/").train()
+    xs = {}
+    for k, s in inputs.items():
+        a = T(pf.normal("%s/%s" % (name, k), s))
+        xs[k] = (nhwc(a) if a.dim() == 4 else a.float().to(dev())).requires_grad_()
+    y = mod(*[xs[k] for k in order])
+    yc = nchw(y) if y.dim() == 4 else y
+    ref = g[name + "/y"]
+    assert relerr(yc, ref) < 1e-4, "output"
+    r = T(pf.uniform(name + "/r", tuple(ref.shape)))
+    (y * (nhwc(r) if r.dim() == 4 else r.float().to(dev()))).sum().backward()
+    for k in inputs:
+        gx = xs[k].grad
+        assert relerr(nchw(gx) if gx.dim() == 4 else gx, g["%s/d_%s" % (name, k)], atol=1e-6) < 5e-4, "d_" + k
+    params = dict(mod.named_parameters())
+    bufs = dict(mod.named_buffers())
+    for k in g.files:
+        if k.startswith(name + "/g/"):
+            assert relerr(params[k[len(name) + 3:]].grad, g[k], atol=1e-5) < 5e-4, k
+        if k.startswith(name + "/b/"):
+            assert relerr(bufs[k[len(name) + 3:]], g[k]) < 1e-5, k
+
+
+def _product_models(tag, cfg):
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    s, c, d = map(int, cfg.split("_"))
+    keys = load_keys(cfg)
+    au, im = G.get_au(s, c, d), G.get_im(s, c, d)
+    au.load_state_dict(filled_sd(keys["au"], tag + "/au/", torch.float32))
+    im.load_state_dict(filled_sd(keys["im"], tag + "/im/", torch.float32))
+    return au.to(dev()), im.to(dev())
+
+
+def _grad_norm_check(mod, ref, tol, floor_frac, what):
+    floor = floor_frac * max(ref.values())
+    params = dict(mod.named_parameters())
+    bad = []
+    for k, v in ref.items():
+        got = float(params[k].grad.double().norm()) if params[k].grad is not None else 0.0
+        if abs(got - v) > tol * max(v, floor):
+            bad.append((k, got, v))
+    assert not bad, "%s: %d/%d grad norms off, first: %s" % (what, len(bad), len(ref), bad[:5])
+
+
+def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3):
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    import tempfile
+    g = load_npz("nets_%s.npz" % tag)
+    meta = load_json("nets_%s.json" % tag)
+    c = meta["config"]
+    au, im = _product_models(tag, cfg)
+    leaked, real, si, z = [t.float().to(dev()) for t in episode(tag, c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
+    with tempfile.TemporaryDirectory() as td:
+        tr = G.GIMImgTrainer(td, c["m"], c["n"], c["k"], au, im, 1e-4, 1e-4, 1e-6, reg_param=0.0)
+    au.train(); im.train()
+    tr.impersonator_opt.zero_grad()
+    loss, fake, out = tr.forward(mode="impersonator_forward", leaked_sample=leaked, si_sample=si, z=z)
+    assert relerr(loss, g["g/loss"]) < tol, "G loss (north_star tolerance 1e-3)"
+    assert relerr(out, g["g/out"]) < tol, "D logits on fake (1e-3)"
+    gf = g["g/fake"]
+    assert relerr(fake[:gf.shape[0], :gf.shape[1]], gf) < tol, "fake images"
+    loss.mean().backward()
+    _grad_norm_check(im, meta["meta"]["g/im_grad_norms"], gtol, floor_frac, "G step")
+    for k in g.files:
+        if k.startswith("g/grad/"):
+            assert relerr(dict(im.named_parameters())[k[7:]].grad, g[k], atol=1e-7) < gtol, k
+    tr.authenticator_opt.zero_grad()
+    res = tr.forward(mode="authenticator_forward", fake_sample=fake.detach(), real_sample=real, si_sample=si)
+    for i, nm in enumerate(["loss", "loss_real", "loss_fake", "reg", "out_real", "out_fake"]):
+        assert relerr(res[i], g["d/" + nm]) < tol or float(np.abs(g["d/" + nm]).max()) == 0.0, nm
+    assert (res[6].cpu().numpy() == g["d/pred_real"]).all() and (res[7].cpu().numpy() == g["d/pred_fake"]).all()
+    res[0].mean().backward()
+    _grad_norm_check(au, meta["meta"]["d/au_grad_norms"], gtol, floor_frac, "D step")
+    for k in g.files:
+        if k.startswith("d/grad/"):
+            assert relerr(dict(au.named_parameters())[k[7:]].grad, g[k], atol=1e-7) < gtol, k
+        if k.startswith("d/buf/"):
+            assert relerr(dict(au.named_buffers())[k[6:]], g[k]) < 1e-4, k
+
+
+def test_tiny_nets_vs_reference_golden():
+    _check_nets("tiny64", "16_1_32", 1e-3, 2e-2)
+
+
+def test_tiny_nets_m2_vs_reference_golden():
+    _check_nets("tiny_m2", "16_1_32", 1e-3, 2e-2)
+
+
+def test_omniglot_shape_vs_reference_golden():
+    """32x32x1, style_dim 512 (BASELINE config 2 shape), B=2 episodes, reference run in fp64."""
+    _check_nets("om32_f64", "32_1_512", 1e-3, 5e-2)
+
+
+def test_voxceleb_shape_vs_reference_golden():
+    """64x64x3, style_dim 512 (BASELINE config 3 shape), B=1 episode, reference run in fp64."""
+    _check_nets("vox64_f64", "64_3_512", 1e-3, 5e-2)
+
+
+@pytest.mark.parametrize("tag", ["reg0", "nau2"])
+def test_trainer_protocol_vs_reference_golden(tag):
+    """Real step protocol (im_train_step / im_eval_step + au_train_step, MultiStepLR, FusedAdam) for consecutive
+    iterations from a conditioned state, against the reference's own loop (fp64)."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    import tempfile
+    g = load_npz("trainer_%s.npz" % tag)
+    meta = load_json("trainer_%s.json" % tag)
+    c = meta["config"]
+    au, im = _product_models(tag, "16_1_32")
+    with tempfile.TemporaryDirectory() as td:
+        tr = G.GIMImgTrainer(td, c["m"], c["n"], c["k"], au, im, au_lr=c["au_lr"], im_lr=c["im_lr"],
+                             env_noise_mapping_lr=c["noise_lr"], lr_milestones=tuple(c["milestones"]), lr_gamma=c["gamma"],
+                             reg_param=c["reg_param"])
+    trainer = G.DataParallelMock(tr)
+    n_steps = len(meta["meta"]["lrs"])
+    for it in range(n_steps):
+        leaked, real, si, z = [t.float().to(dev()) for t in
+                               episode("%s/it%d" % (tag, it), c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
+        tr.do_global_step()
+        tr.update_learning_rate()
+        lrs = meta["meta"]["lrs"][it]
+        assert abs(tr.au_lr - lrs[0]) < 1e-12 and abs(tr.im_lr - lrs[1]) < 1e-12 and abs(tr.im_noise_mapping_lr - lrs[2]) < 1e-12
+        assert tr.global_step == lrs[3]
+        if (tr.global_step + 1) % c["n_au_steps"] == 0:
+            gres = G.im_train_step(trainer, leaked, si, z=z)
+        else:
+            gres = G.im_eval_step(trainer, leaked, si, z=z)
+        dres = G.au_train_step(trainer, real, gres[1], si)
+        # Adam with beta1 = 0 moves every weight by ~lr per step whatever the gradient size, so fp32 rounding of
+        # near-zero gradients shows up after the first update: 1e-3 on step 0, looser afterwards
+        tol = 1e-3 if it == 0 else 2e-2
+        assert relerr(gres[0], g["it%d/g_loss" % it]) < tol, (it, "g_loss")
+        assert relerr(gres[2], g["it%d/g_out" % it]) < tol, (it, "g_out")
+        assert relerr(gres[1], g["it%d/fake" % it]) < tol, (it, "fake")
+        for i, nm in enumerate(["loss", "loss_real", "loss_fake", "reg", "out_real", "out_fake"]):
+            ref = g["it%d/d_%s" % (it, nm)]
+            assert relerr(dres[i], ref) < tol or float(np.abs(ref).max()) == 0.0, (it, nm)
+    assert meta["meta"]["au_opt_n_state"] == len(tr.authenticator_opt.state_dict()["state"])
+    assert len(tr.impersonator_opt.param_groups) == meta["meta"]["im_opt_n_groups"]
+
+
+def test_product_vs_oracle_fp32_step_and_state():
+    """One full gim_step on the tiny config vs the oracle (fp64) on identical inputs: parameters after the
+    update, Adam moments, spectral-norm buffers."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    import tempfile
+    tag, cfg = "pvo", "16_1_32"
+    B, m, n, k, c, s, d = 2, 1, 3, 4, 1, 16, 32
+    keys = load_keys(cfg)
+    au_o = filled_sd(keys["au"], tag + "/au/")
+    im_o = filled_sd(keys["im"], tag + "/im/")
+    otr = go.OracleTrainer(au_o, im_o, n, 1e-3, 1e-3, 1e-4)
+    au, im = _product_models(tag, cfg)
+    with tempfile.TemporaryDirectory() as td:
+        tr = G.GIMImgTrainer(td, m, n, k, au, im, 1e-3, 1e-3, 1e-4, reg_param=0.0)
+    trainer = G.DataParallelMock(tr)
+    leaked, real, si, z = episode(tag, B, m, n, k, c, s, d)
+    (g_o, d_o) = otr.step(leaked, real, si, z)
+    gi, di = G.gim_step(trainer, *[t.float().to(dev()) for t in (leaked, real, si)], z=z.float().to(dev()))
+    assert relerr(gi[0], g_o[0].mean()) < 1e-3 and relerr(gi[2], g_o[2]) < 1e-3 and relerr(gi[1], g_o[1]) < 1e-3
+    assert relerr(di[0], d_o[0].mean()) < 1e-3 and relerr(di[4], d_o[4].mean()) < 1e-3
+    # parameters moved by ~lr each (beta1 = 0): compare the UPDATE direction where the gradient is not noise
+    bad = []
+    for name, mod, sd_o, opt_o in (("au", au, au_o, otr.au_opt), ("im", im, im_o, otr.im_opt)):
+        for kk, p in mod.named_parameters():
+            if kk not in opt_o.state:
+                continue
+            gn = float(opt_o.state[kk]["v"].sqrt().mean())
+            if gn < 1e-6:
+                continue
+            if relerr(p, sd_o[kk]) > 2e-3:
+                bad.append((name, kk, relerr(p, sd_o[kk])))
+        for kk, b in mod.named_buffers():
+            assert relerr(b, sd_o[kk]) < 1e-3, (name, kk)
+    assert len(bad) <= 3, bad[:10]

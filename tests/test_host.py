@@ -1,0 +1,175 @@
+"""CPU suite (no GPU): host logic of the product package, the C-ABI library's exports, and the
+data-parallel sharding / gradient exchange over gloo with world_size 2."""
+import ctypes
+import os
+import re
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from tests.helpers import load_keys  # noqa: E402
+
+
+def test_state_dict_keys_match_reference():
+    """Names, shapes and ORDER of every state-dict entry and parameter equal the reference's (captured by
+    oracle/make_golden.py), incl. the spectral-norm weight_orig / weight_u / weight_v triple."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    for cfg in ("16_1_32", "32_1_512"):
+        s, c, d = map(int, cfg.split("_"))
+        ref = load_keys(cfg)
+        au, im = G.get_au(s, c, d), G.get_im(s, c, d)
+        assert [[k, list(v.shape)] for k, v in au.state_dict().items()] == ref["au"]
+        assert [[k, list(v.shape)] for k, v in im.state_dict().items()] == ref["im"]
+        assert [k for k, _ in au.named_parameters()] == ref["au_params"]
+        assert [k for k, _ in im.named_parameters()] == ref["im_params"]
+        groups = [len(list(getattr(im, g).parameters())) for g in
+                  ("src_encoder", "env_encoder", "env_decoder", "img2img", "img_att", "env_noise_mapper")]
+        assert groups == ref["im_groups"]
+
+
+def test_conv_weights_are_stored_channels_last():
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    au = G.get_au(16, 1, 32)
+    w = au.src_encoder.down_blocks[0].conv_r2.weight_orig
+    assert w.shape == (32, 32, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+    sd = {k: v.clone() for k, v in au.state_dict().items()}
+    au.load_state_dict(sd)  # plain NCHW-contiguous checkpoints load; storage stays channels-last
+    assert au.src_encoder.down_blocks[0].conv_r2.weight_orig.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_trainer_host_protocol():
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    au, im = G.get_au(16, 1, 32), G.get_im(16, 1, 32)
+    with tempfile.TemporaryDirectory() as td:
+        tr = G.GIMImgTrainer(td, 1, 3, 4, au, im, au_lr=2e-3, im_lr=1e-3, env_noise_mapping_lr=1e-4,
+                             lr_milestones=(2,), lr_gamma=0.5, reg_param=0.0)
+        assert os.path.isdir(os.path.join(td, "ckpts"))
+        assert tr.global_step == -1
+        assert len(tr.impersonator_opt.param_groups) == 6 and len(tr.authenticator_opt.param_groups) == 1
+        assert tr.impersonator_opt.param_groups[-1]["lr"] == 1e-4
+        assert tr.authenticator_opt.param_groups[0]["betas"] == (0.0, 0.99)
+        lrs = []
+        for _ in range(3):
+            tr.do_global_step()
+            tr.update_learning_rate()
+            lrs.append((tr.au_lr, tr.im_lr, tr.im_noise_mapping_lr, tr.global_step))
+        # MultiStepLR built with last_epoch=-1 and stepped before the optimiser: counter = it + 1
+        assert lrs == [(2e-3, 1e-3, 1e-4, 0), (1e-3, 5e-4, 5e-5, 1), (1e-3, 5e-4, 5e-5, 2)]
+        with pytest.raises(ValueError):
+            tr.forward(mode="nope")
+        tr.save(epoch=3)
+        path = os.path.join(td, "ckpts", "model_%08d.pt" % 2)
+        ck = torch.load(path, weights_only=False)
+        assert set(ck) == {"global_step", "last_epoch", "authenticator", "impersonator", "authenticator_opt", "impersonator_opt"}
+        assert ck["global_step"] == {"global_step": 2} and ck["last_epoch"] == 3
+        au2, im2 = G.get_au(16, 1, 32), G.get_im(16, 1, 32)
+        tr2 = G.GIMImgTrainer(td, 1, 3, 4, au2, im2, 2e-3, 1e-3, 1e-4, reg_param=0.0)
+        tr2.resume_from_ckpt(path)
+        assert tr2.global_step == 2
+        for (k, a), (_, b) in zip(au.state_dict().items(), au2.state_dict().items()):
+            assert torch.equal(a, b), k
+
+
+def test_no_cpu_compute_path():
+    """The product must fail loudly without the GPU: no silent CPU fallback anywhere."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
+    au = G.get_au(16, 1, 32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        au(torch.zeros(1, 2, 1, 16, 16), torch.zeros(1, 2, 1, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(3))
+    opt = G.FusedAdam(au.parameters(), lr=1e-3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "optimalstrategiesagainstgenerativeattacks_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "gim_oracle" not in src, f
+
+
+def test_library_exports_every_header_symbol():
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    header = open(os.path.join(ROOT, "include", "gim_hip.h")).read()
+    declared = set(re.findall(r"\b(gim_[a-z0-9_]+)\s*\(", header))
+    declared -= {"gim_conv_shape"}
+    assert len(declared) >= 30
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libgim_hip.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES) | {"gim_last_error"}, declared ^ (set(_lib.SIGNATURES) | {"gim_last_error"})
+    assert lib.gim_version() >= 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# data parallelism over episodes: gloo, world_size 2
+# ---------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from oracle import gim_oracle as go
+    from optimalstrategiesagainstgenerativeattacks_amd.optim import all_reduce_grads_
+    from optimalstrategiesagainstgenerativeattacks_amd.training_utils import EpisodeParallel
+    from tests.helpers import episode, filled_sd
+    keys = load_keys("16_1_32")
+    au = filled_sd(keys["au"], "dp/au/")
+    go.set_requires_grad(au)
+    B, n, k = 4, 2, 3
+    _, real, si, _ = episode("dp", B, 1, n, k, 1, 16, 32)
+    fake = real.flip(0).contiguous()
+    ep = EpisodeParallel(module=None)
+    assert (ep.rank, ep.world_size) == (rank, world)
+    real_l, fake_l, si_l = ep.shard(real, fake, si)
+    assert real_l.shape[0] == B // world
+    loss = go.authenticator_forward(au, fake_l, real_l, si_l, True, 0.0)[0].mean()  # local mean, as au_train_step does
+    loss.backward()
+    names = [kk for kk in au if go.is_param(kk)]
+    flat = torch.cat([au[kk].grad.reshape(-1) for kk in names])
+    scale = all_reduce_grads_(flat)
+    flat = flat * scale
+    if rank == 0:
+        q.put((flat, [au[kk].detach().clone() for kk in ("src_encoder.down_blocks.0.conv_r1.weight_u",)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_episode_data_parallel_equals_big_batch_gloo():
+    """Sharding the episode batch over 2 ranks + one all-reduce(sum) of the flat gradient bucket (scaled by
+    1/world) equals the single-process gradient of the whole batch; spectral-norm buffers need no sync."""
+    from oracle import gim_oracle as go
+    from tests.helpers import episode, filled_sd, relerr
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat_dp, bufs = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    keys = load_keys("16_1_32")
+    au = filled_sd(keys["au"], "dp/au/")
+    go.set_requires_grad(au)
+    _, real, si, _ = episode("dp", 4, 1, 2, 3, 1, 16, 32)
+    fake = real.flip(0).contiguous()
+    go.authenticator_forward(au, fake, real, si, True, 0.0)[0].mean().backward()
+    flat = torch.cat([au[kk].grad.reshape(-1) for kk in au if go.is_param(kk)])
+    assert relerr(flat_dp, flat) < 1e-10
+    assert relerr(bufs[0], au["src_encoder.down_blocks.0.conv_r1.weight_u"]) < 1e-12
