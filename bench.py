@@ -1,0 +1,208 @@
+"""GIM episodes/s on MI355X: one "step" = one training iteration of the hot path on one episode batch
+(generator step + discriminator step, both Adam updates; training/gim_img_training.py:225-239) over synthetic
+inputs already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vox64|om32] [--batch B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job episodes/s, the MFMA roofline
+fraction of the step (ALGO FLOP/episode x episodes / time / fp32-MFMA peak), the dominant
+kernel's own roofline from a HIP-event microbenchmark through the C ABI, and the CPU baseline (the oracle, a
+port of the reference's path, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# forward unit costs in GFLOP (2*MAC; conv + linear + attention bmm), style_dim = 512
+UNIT = {
+    "om32": dict(S=32, C=1, E=1.2570, M=0.00210, Dec=0.2274, I2I=5.0189, FC=0.00944, H0=0.01468),
+    "vox64": dict(S=64, C=3, E=1.7564, M=0.00210, Dec=0.9583, I2I=6.0770, FC=0.00944, H0=0.01468),
+}
+
+
+def algo_gflop_per_episode(w, m, n, k):
+    """ALGO = 3*F_im + F_auG + (2nE + H) + 3*F_auD  (SURVEY.md 8(d))."""
+    u = UNIT[w]
+    F_im = 2 * m * u["E"] + n * (u["M"] + u["Dec"] + u["I2I"])
+    H = (n + k) * u["FC"] + u["H0"]
+    F_auG = 2 * (n + k) * u["E"] + H
+    F_auD = 2 * (k + 2 * n) * u["E"] + 2 * H
+    return 3 * F_im + F_auG + (2 * n * u["E"] + H) + 3 * F_auD
+
+
+def synthetic_batch(B, m, n, k, C, S, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    mk = lambda t: (torch.rand((B, t, C, S, S), generator=g) * 2 - 1).to(device)  # noqa: E731  dataset range is [-1, 1]
+    return mk(m), mk(n), mk(k)
+
+
+def build_trainer(S, C, n, m, k, device, style_dim=512):
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    torch.manual_seed(1)  # train_gim_on_imgs.py:6
+    au, im = G.get_au(S, C, style_dim).to(device), G.get_im(S, C, style_dim).to(device)
+    with tempfile.TemporaryDirectory() as td:
+        tr = G.GIMImgTrainer(td, m, n, k, au, im, au_lr=1e-4, im_lr=1e-4, env_noise_mapping_lr=1e-6, beta1=0.0, beta2=0.99,
+                             reg_param=0.0)
+    return G, tr
+
+
+def dominant_kernel_roofline(device):
+    """HIP-event timing of the heaviest convolution of the workload through the C ABI: the encoder's
+    64->64 3x3 conv at 64x64 on the D-step image count (320 images): fwd, dgrad, wgrad."""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    lib = _lib.load()
+    N, H, Cin, Cout, K = 320, 64, 64, 64, 3
+    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, 0, 0.2)
+    x = torch.randn(N, H, H, Cin, device=device)
+    w = torch.randn(Cout, K, K, Cin, device=device) * 0.05
+    y = torch.empty(N, H, H, Cout, device=device)
+    dx = torch.empty_like(x)
+    ns = lib.gim_conv2d_wgrad_slabs(sh)
+    slabs = torch.empty(ns * Cout * K * K * Cin, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    flops = 2.0 * N * H * H * Cout * Cin * K * K
+    out = {}
+    for name, fn in (("fwd", lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st)),
+                     ("dgrad", lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)),
+                     ("wgrad", lambda: lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), ns, sh, st))):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 10
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[name] = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2)}
+    return {"kernel": "conv_igemm 64->64 3x3 @64x64 x320 img (fp32 MFMA)", "gflop_per_launch": round(flops / 1e9, 2), **out,
+            "frac_fwd": round(out["fwd"]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+
+def cpu_baseline(workload, m, n, k, sample_B):
+    """The oracle (CPU port of the reference's path, parity-pinned by tests/golden) on a bounded sample."""
+    from oracle import gim_oracle as go
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    u = UNIT[workload]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    au, im = G.get_au(u["S"], u["C"], 512), G.get_im(u["S"], u["C"], 512)
+    au_sd = {kk: v.detach().clone().contiguous() for kk, v in au.state_dict().items()}
+    im_sd = {kk: v.detach().clone().contiguous() for kk, v in im.state_dict().items()}
+    otr = go.OracleTrainer(au_sd, im_sd, n, 1e-4, 1e-4, 1e-6)
+    leaked, real, si = synthetic_batch(sample_B, m, n, k, u["C"], u["S"], "cpu", 1234)
+    z = torch.randn(sample_B, n, 512)
+    otr.step(leaked, real, si, z)  # warm-up
+    t0 = time.time()
+    otr.step(leaked, real, si, z)
+    dt = time.time() - t0
+    return {"value": round(sample_B / dt, 4), "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": "1 timed step (after 1 warm-up) of B=%d episodes of the same workload, torch-CPU eager fp32, %d threads"
+                      % (sample_B, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="vox64", choices=sorted(UNIT))
+    ap.add_argument("--batch", type=int, default=0, help="episodes per GPU (default: 16 for vox64, 32 for om32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-bench", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    m, n, k = 1, 5, 10
+    u = UNIT[args.workload]
+    B = args.batch or (16 if args.workload == "vox64" else 32)
+    G, tr = build_trainer(u["S"], u["C"], n, m, k, device)
+    trainer = G.EpisodeParallel(tr)
+    trainer.broadcast_parameters()
+    leaked, real, si = synthetic_batch(B, m, n, k, u["C"], u["S"], device, 1234 + rank)
+    zgen = torch.Generator(device=device).manual_seed(4321 + rank)
+
+    def step():
+        z = torch.randn((B, n, 512), device=device, generator=zgen)
+        tr.do_global_step()
+        tr.update_learning_rate()
+        return G.gim_step(trainer, leaked, real, si, z=z)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    import warnings
+    warnings.filterwarnings("ignore")
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.time()
+    ev0.record()
+    for _ in range(args.steps):
+        out = step()
+    ev1.record()
+    fence()
+    dt = time.time() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    g_loss, d_loss = float(out[0][0]), float(out[1][0])
+
+    if rank == 0:
+        eps = B * world * args.steps / dt
+        algo = algo_gflop_per_episode(args.workload, m, n, k)
+        achieved = eps * algo / 1e3 / world  # TFLOP/s per GPU
+        line = {
+            "metric": "GIM episodes/sec (%dx%dx%d, m=%d n=%d k=%d)" % (u["S"], u["S"], u["C"], m, n, k),
+            "value": round(eps, 3), "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %dx%dx%d synthetic episodes, m=%d n=%d k=%d, %d episodes/GPU, style_dim=512, "
+                                   "G step + D step + 2 Adam updates per step, reg_param=0" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B),
+                       "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "algo_gflop_per_episode": round(algo, 1), "device_ms_per_step": round(dev_ms / args.steps, 3)},
+            "final_losses": {"g": round(g_loss, 5), "d": round(d_loss, 5)},
+        }
+        if not args.no_kernel_bench:
+            line["dominant_kernel"] = dominant_kernel_roofline(device)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, m, n, k, sample_B=2)
+            line["cpu_baseline"]["gpu_over_cpu"] = round(eps / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

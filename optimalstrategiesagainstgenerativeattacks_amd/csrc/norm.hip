@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
         } else {
             const float sd = sqrtf(ssq[e] / (float)(HW - 1));
             d = sd + eps;
-            c2 = 1.0f / ((float)(HW - 1) * sd);
+            c2 = sd > 0.f ? 1.0f / ((float)(HW - 1) * sd) : 0.f;  // zero-variance map: no gradient through the std
         }
         invd[e] = 1.0f / d;
         const long long pi = (mode == 0) ? (long long)(c + e) : (long long)n * C + c + e;

@@ -45,3 +45,11 @@ def load_npz(name):
 def load_json(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)
+
+
+def relerr_floor(a, b, floor):
+    """||a-b|| / (||b|| + floor): for families of gradients where some members are mathematically zero
+    (conv bias in front of a norm layer, attention f-bias): `floor` is set from the family's largest norm."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + floor))

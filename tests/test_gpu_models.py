@@ -7,7 +7,7 @@ import torch
 
 from oracle import gim_oracle as go
 from oracle import portable_fill as pf
-from tests.helpers import T, episode, filled_sd, load_json, load_keys, load_npz, relerr
+from tests.helpers import T, episode, filled_sd, load_json, load_keys, load_npz, relerr, relerr_floor
 
 pytestmark = pytest.mark.gpu
 
@@ -67,9 +67,10 @@ def test_block_vs_reference_golden(name):
         assert relerr(nchw(gx) if gx.dim() == 4 else gx, g["%s/d_%s" % (name, k)], atol=1e-6) < 5e-4, "d_" + k
     params = dict(mod.named_parameters())
     bufs = dict(mod.named_buffers())
+    gmax = max(float(np.linalg.norm(g[k])) for k in g.files if k.startswith(name + "/g/"))
     for k in g.files:
         if k.startswith(name + "/g/"):
-            assert relerr(params[k[len(name) + 3:]].grad, g[k], atol=1e-5) < 5e-4, k
+            assert relerr_floor(params[k[len(name) + 3:]].grad, g[k], 1e-3 * gmax) < 5e-4, k
         if k.startswith(name + "/b/"):
             assert relerr(bufs[k[len(name) + 3:]], g[k]) < 1e-5, k
 
