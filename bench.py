@@ -31,6 +31,14 @@ UNIT = {
 }
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def algo_gflop_per_episode(w, m, n, k):
     """ALGO = 3*F_im + F_auG + (2nE + H) + 3*F_auD  (SURVEY.md 8(d))."""
     u = UNIT[w]
@@ -75,7 +83,7 @@ def dominant_kernel_roofline(device):
     out = {}
     for name, fn in (("fwd", lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st)),
                      ("dgrad", lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)),
-                     ("wgrad", lambda: lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), ns, sh, st))):
+                     ("wgrad", lambda: lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st))):
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -96,7 +104,8 @@ def cpu_baseline(workload, m, n, k, sample_B):
     from oracle import gim_oracle as go
     import optimalstrategiesagainstgenerativeattacks_amd as G
     u = UNIT[workload]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    # the GPU box gives one GPU a 16-CPU share whatever the affinity mask says: more threads only oversubscribe
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
     torch.set_num_threads(cores)
     torch.manual_seed(1)
     au, im = G.get_au(u["S"], u["C"], 512), G.get_im(u["S"], u["C"], 512)
@@ -158,8 +167,11 @@ def main():
 
     import warnings
     warnings.filterwarnings("ignore")
-    for _ in range(args.warmup):
+    log("models built; warm-up")
+    for i in range(args.warmup):
         out = step()
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.time()
@@ -170,6 +182,7 @@ def main():
     fence()
     dt = time.time() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    log("timed region done: %.3f s for %d steps" % (dt, args.steps))
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -195,8 +208,10 @@ def main():
         }
         if not args.no_kernel_bench:
             line["dominant_kernel"] = dominant_kernel_roofline(device)
+            log("kernel microbenchmark done")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, m, n, k, sample_B=2)
+            log("cpu baseline done")
             line["cpu_baseline"]["gpu_over_cpu"] = round(eps / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line))
     if world > 1:

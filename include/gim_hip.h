@@ -56,17 +56,21 @@ int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const 
                      const gim_conv_shape* s, void* stream);
 
 /* Split-K weight gradient: slabs[i] ([Cout][KH][KW][Cin] each) for i < n_slabs hold partial sums over
- * disjoint pixel ranges of  dy^T * im2col(x~).  n_slabs from gim_conv2d_wgrad_slabs(). */
+ * disjoint pixel ranges of  dy^T * im2col(x~);  bias_slabs[i] ([Cout] each, may be NULL) the matching partial
+ * sums of dy over pixels (the bias gradient, produced from the dy tiles the kernel streams anyway).
+ * n_slabs from gim_conv2d_wgrad_slabs(). */
 int gim_conv2d_wgrad_slabs(const gim_conv_shape* s);
-int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, int n_slabs, const gim_conv_shape* s, void* stream);
+int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs, const gim_conv_shape* s,
+                     void* stream);
 
-/* Finish a weight gradient: g = sum_i slabs[i];
+/* Finish a weight gradient: g = sum_i slabs[i]; db = sum_i bias_slabs[i] (if db != NULL);
  *   sigma == NULL : dw = g                                   (plain nn.Linear weight)
  *   else          : dw = g / sigma - (<g, w> / sigma^2) u v^T (autograd through torch spectral_norm's
  *                   weight = weight_orig / (u^T W v) with u, v constants).
  * u [Cout]; v [Cin*KH*KW] in the REFERENCE's flattening order (ci, kh, kw).  scratch: >= 512 floats. */
-int gim_wgrad_finish(const float* slabs, int n_slabs, const float* w, const float* sigma, const float* u, const float* v,
-                     float* dw, float* scratch, int Cout, int Cin, int KH, void* stream);
+int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int n_slabs, const float* w, const float* sigma,
+                     const float* u, const float* v, float* dw, float* db, float* scratch, int Cout, int Cin, int KH,
+                     void* stream);
 
 /* One power iteration of torch.nn.utils.spectral_norm (n_power_iterations=1, eps=1e-12, dim=0):
  *   v <- normalize(W^T u); u <- normalize(W v); sigma = u^T W v.       (training = 1)

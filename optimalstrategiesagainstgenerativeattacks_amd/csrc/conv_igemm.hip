@@ -36,14 +36,21 @@ struct ConvP {
     float pre_slope, mask_slope;
 };
 
-template <int BM, int BN, int TM, int TN, int BMODE, bool GEN>
+// GENF bit 0: generic K (channel count of the gathered tensor not a multiple of 16, or unaligned base)
+// GENF bit 1: (BMODE 1 only) scalar loads of the k-major weight tile (output channels not a multiple of 4)
+template <int BM, int BN, int TM, int TN, int BMODE, int GENF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+    constexpr bool GEN = (GENF & 1) != 0;
+    constexpr bool BSCALAR = (GENF & 2) != 0;
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int A_ROWS = BM / 64;
     constexpr int B_ROWS = (BN + 63) / 64;         // BMODE 0
-    constexpr int B_PER = BK * BN / 256;           // BMODE 1
+    constexpr int B_PER = BK * BN / 256;           // BMODE 1, scalar
+    constexpr int B_U = BN / 4;                    // BMODE 1, vector: float4 units per k-row
+    constexpr int B_RSTEP = 256 / B_U;
+    constexpr int B_PER4 = (BK + B_RSTEP - 1) / B_RSTEP;
     constexpr int A_SZ = BM * LDK;
     constexpr int B_SZ = (BMODE == 0) ? BN * LDK : BK * BN;
     __shared__ __attribute__((aligned(16))) float lds[2 * A_SZ + 2 * B_SZ];
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     f32x4 ra[A_ROWS];
     f32x4 rb0[B_ROWS];
     float rb1[B_PER];
+    f32x4 rb4[B_PER4];
 
     auto load_tiles = [&](int k0) {
         // ---- A: gathered activations ----
@@ -135,24 +143,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 tap_u = k0 / p.Ca;
                 c0_u = k0 - tap_u * p.Ca;
             }
+            if constexpr (BSCALAR) {
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int idx = t + 256 * i;
-                const int krow = idx / BN, col = idx % BN;
-                int tap, ca;
-                bool v = true;
-                if constexpr (!GEN) {
-                    tap = tap_u;
-                    ca = c0_u + krow;
-                } else {
-                    const int kf = k0 + krow;
-                    tap = kf / p.Ca;
-                    ca = kf - tap * p.Ca;
-                    v = kf < p.Ktot;
+                for (int i = 0; i < B_PER; ++i) {
+                    const int idx = t + 256 * i;
+                    const int krow = idx / BN, col = idx % BN;
+                    int tap, ca;
+                    bool v = true;
+                    if constexpr (!GEN) {
+                        tap = tap_u;
+                        ca = c0_u + krow;
+                    } else {
+                        const int kf = k0 + krow;
+                        tap = kf / p.Ca;
+                        ca = kf - tap * p.Ca;
+                        v = kf < p.Ktot;
+                    }
+                    const int ci = n0 + col;
+                    v = v && ci < p.Cb;
+                    rb1[i] = v ? p.w[((long long)ca * p.T + (p.T - 1 - tap)) * p.Cin_w + ci] : 0.f;
                 }
-                const int ci = n0 + col;
-                v = v && ci < p.Cb;
-                rb1[i] = v ? p.w[((long long)ca * p.T + (p.T - 1 - tap)) * p.Cin_w + ci] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PER4; ++i) {
+                    const int krow = t / B_U + i * B_RSTEP, col = (t % B_U) * 4;
+                    int tap, ca;
+                    bool v = krow < BK;
+                    if constexpr (!GEN) {
+                        tap = tap_u;
+                        ca = c0_u + krow;
+                    } else {
+                        const int kf = k0 + krow;
+                        tap = kf / p.Ca;
+                        ca = kf - tap * p.Ca;
+                        v = v && kf < p.Ktot;
+                    }
+                    const int ci = n0 + col;
+                    v = v && ci < p.Cb;  // Cb % 4 == 0 on this path: the whole quad is in range
+                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                    if (v) val = *reinterpret_cast<const f32x4*>(p.w + ((long long)ca * p.T + (p.T - 1 - tap)) * p.Cin_w + ci);
+                    rb4[i] = val;
+                }
             }
         }
     };
@@ -168,8 +199,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 if (row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
             }
         } else {
+            if constexpr (BSCALAR) {
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) Bs[buf * B_SZ + t + 256 * i] = rb1[i];  // [krow][col] row-major == idx
+                for (int i = 0; i < B_PER; ++i) Bs[buf * B_SZ + t + 256 * i] = rb1[i];  // [krow][col] row-major == idx
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PER4; ++i) {
+                    const int krow = t / B_U + i * B_RSTEP, col = (t % B_U) * 4;
+                    if (krow < BK) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + krow * BN + col]) = rb4[i];
+                }
+            }
         }
     };
 
@@ -248,6 +287,7 @@ struct WgP {
     const float* dy;
     const float* x;
     float* slabs;
+    float* bias_slabs;
     int N, H, W, logH, logW;
     int Cin, Cout;
     int KH, pad, ups, T;
@@ -257,15 +297,20 @@ struct WgP {
     float pre_slope;
 };
 
-template <int BM, int BN, int TM, int TN>
+// VEC = 4: dY rows and gathered x rows are fetched as float4 (Cout % 4 == 0, Cin % 4 == 0, 16-byte aligned
+// bases); VEC = 1: scalar fallback (3- and 6-channel image layers, 1-channel Omniglot).
+// Workgroups of the first column tile also produce the bias gradient sum_m dY[m][co] of their pixel slice from
+// the dY values they stream anyway (bias_slabs[slice][Cout]).
+template <int BM, int BN, int TM, int TN, int VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    constexpr int A_PER = BK * BM / 256, B_PER = BK * BN / 256;
-    constexpr int A_STEP = 256 / BM, B_STEP = 256 / BN;
-    __shared__ float As[2][BK * BM];
-    __shared__ float Bs[2][BK * BN];
+    constexpr int AU = BM / VEC, BU = BN / VEC;                 // load units per tile row
+    constexpr int A_RSTEP = 256 / AU, B_RSTEP = 256 / BU;       // tile rows covered per pass
+    constexpr int A_PER = (BK + A_RSTEP - 1) / A_RSTEP, B_PER = (BK + B_RSTEP - 1) / B_RSTEP;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
     const int t = threadIdx.x;
     const int j0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
@@ -273,40 +318,85 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     const int mend = min(p.M, mbeg + p.mper);
     const int Hs = p.H >> p.ups, Ws = p.W >> p.ups;
 
-    const int ac = t % BM, ak = t / BM;
+    const int ac = (t % AU) * VEC, ak = t / AU;
     const bool a_cok = (co0 + ac) < p.Cout;
-    const int bc = t % BN, bk = t / BN;
+    const int bc = (t % BU) * VEC, bk = t / BU;
     const int j = j0 + bc;
     const bool b_jok = j < p.Kcols;
     const int tap = b_jok ? j / p.Cin : 0;
     const int ci = b_jok ? j - tap * p.Cin : 0;
     const int kh = tap / p.KH, kw = tap - kh * p.KH;
     const int dh = kh - p.pad, dw = kw - p.pad;
+    const bool do_bias = p.bias_slabs != nullptr && blockIdx.x == 0;
 
-    float ra[A_PER], rb[B_PER];
+    float ra[A_PER][VEC], rb[B_PER][VEC];
+    float bsum[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) bsum[e] = 0.f;
+
     auto load_tiles = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int m = mb + ak + i * A_STEP;
-            ra[i] = (a_cok && m < mend) ? p.dy[(long long)m * p.Cout + co0 + ac] : 0.f;
+            const int row = ak + i * A_RSTEP;
+            const int m = mb + row;
+            const bool v = a_cok && row < BK && m < mend;
+            if constexpr (VEC == 4) {
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (v) val = *reinterpret_cast<const f32x4*>(p.dy + (long long)m * p.Cout + co0 + ac);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[i][e] = val[e];
+            } else {
+                ra[i][0] = v ? p.dy[(long long)m * p.Cout + co0 + ac] : 0.f;
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) bsum[e] += ra[i][e];
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
-            const int m = mb + bk + i * B_STEP;
+            const int row = bk + i * B_RSTEP;
+            const int m = mb + row;
             const int n = m >> (p.logH + p.logW);
             const int ih = ((m >> p.logW) & (p.H - 1)) + dh;
             const int iw = (m & (p.W - 1)) + dw;
-            const bool v = b_jok && m < mend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            float val = 0.f;
-            if (v) val = lrelu_f(p.x[((long long)(n * Hs + (ih >> p.ups)) * Ws + (iw >> p.ups)) * p.Cin + ci], p.pre_slope);
-            rb[i] = val;
+            const bool v = b_jok && row < BK && m < mend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const long long off = ((long long)(n * Hs + (ih >> p.ups)) * Ws + (iw >> p.ups)) * p.Cin + ci;
+            if constexpr (VEC == 4) {
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (v) val = *reinterpret_cast<const f32x4*>(p.x + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[i][e] = lrelu_f(val[e], p.pre_slope);
+            } else {
+                rb[i][0] = v ? lrelu_f(p.x[off], p.pre_slope) : 0.f;
+            }
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) As[buf][t + 256 * i] = ra[i];
+        for (int i = 0; i < A_PER; ++i) {
+            const int row = ak + i * A_RSTEP;
+            if (row < BK) {
+                if constexpr (VEC == 4) {
+                    f32x4 val = {ra[i][0], ra[i][1], ra[i][2], ra[i][3]};
+                    *reinterpret_cast<f32x4*>(&As[buf][row * BM + ac]) = val;
+                } else {
+                    As[buf][row * BM + ac] = ra[i][0];
+                }
+            }
+        }
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) Bs[buf][t + 256 * i] = rb[i];
+        for (int i = 0; i < B_PER; ++i) {
+            const int row = bk + i * B_RSTEP;
+            if (row < BK) {
+                if constexpr (VEC == 4) {
+                    f32x4 val = {rb[i][0], rb[i][1], rb[i][2], rb[i][3]};
+                    *reinterpret_cast<f32x4*>(&Bs[buf][row * BN + bc]) = val;
+                } else {
+                    Bs[buf][row * BN + bc] = rb[i][0];
+                }
+            }
+        }
     };
 
     const int lane = t & 63, r = lane & 31, h = lane >> 5, wv = t >> 6;
@@ -358,6 +448,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
                 if (co < p.Cout) out[(long long)co * p.Kcols + col] = acc[i][jj][e];
             }
         }
+
+    if (do_bias) {  // block-uniform; As is free after the loop's last barrier
+        float* red = &As[0][0];  // needs (256 / AU) * BM = 256 * VEC <= 2 * BK * BM floats
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[ak * BM + ac + e] = bsum[e];
+        __syncthreads();
+        if (t < BM && co0 + t < p.Cout) {
+            float sacc = 0.f;
+            for (int rr = 0; rr < 256 / AU; ++rr) sacc += red[rr * BM + t];
+            p.bias_slabs[(long long)blockIdx.z * p.Cout + co0 + t] = sacc;
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -376,7 +478,7 @@ static int fill_common(const gim_conv_shape* s, int* logH, int* logW) {
     return GIM_OK;
 }
 
-template <int BMODE, bool GEN>
+template <int BMODE, int GEN>
 static void launch_igemm(const ConvP& p, hipStream_t st) {
     const int M = p.M, Cb = p.Cb;
     if (Cb > 64) {
@@ -422,8 +524,8 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     p.Cin_w = s->Cin; p.M = s->N * s->H * s->W; p.Ktot = p.T * s->Cin;
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f;
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
-    if (gen) launch_igemm<0, true>(p, (hipStream_t)stream);
-    else launch_igemm<0, false>(p, (hipStream_t)stream);
+    if (gen) launch_igemm<0, 1>(p, (hipStream_t)stream);
+    else launch_igemm<0, 0>(p, (hipStream_t)stream);
     return gim_check_launch("gim_conv2d_fwd");
 }
 
@@ -441,8 +543,10 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
     p.Cin_w = s->Cin; p.M = s->N * s->H * s->W; p.Ktot = p.T * s->Cout;
     p.pre_slope = 1.f; p.mask_slope = s->pre_slope;
     const bool gen = (s->Cout % BK) != 0 || ((uintptr_t)dy & 15);
-    if (gen) launch_igemm<1, true>(p, (hipStream_t)stream);
-    else launch_igemm<1, false>(p, (hipStream_t)stream);
+    const bool bscalar = (s->Cin % 4) != 0 || ((uintptr_t)w & 15);
+    hipStream_t st = (hipStream_t)stream;
+    if (gen) { if (bscalar) launch_igemm<1, 3>(p, st); else launch_igemm<1, 1>(p, st); }
+    else     { if (bscalar) launch_igemm<1, 2>(p, st); else launch_igemm<1, 0>(p, st); }
     return gim_check_launch("gim_conv2d_dgrad");
 }
 
@@ -452,8 +556,10 @@ static void wgrad_plan(const gim_conv_shape* s, int* bm, int* bn, int* nslab, in
     *bm = s->Cout > 64 ? 128 : (s->Cout > 32 ? 64 : 32);
     *bn = (*bm == 32) ? 128 : (Kcols > 64 ? 128 : 64);
     const long long tiles = (long long)((Kcols + *bn - 1) / *bn) * ((s->Cout + *bm - 1) / *bm);
-    long long S = (1024 + tiles - 1) / tiles;
-    const long long maxS = (M + 255) / 256;
+    // about two workgroups per CU in total, and at least 32 K-steps (512 pixels) per workgroup so that the
+    // slab write + later slab reduction stay small next to the MFMA work
+    long long S = (512 + tiles - 1) / tiles;
+    const long long maxS = (M + 511) / 512;
     if (S > maxS) S = maxS;
     if (S > 256) S = 256;
     if (S < 1) S = 1;
@@ -471,7 +577,17 @@ extern "C" int gim_conv2d_wgrad_slabs(const gim_conv_shape* s) {
     return ns;
 }
 
-extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, int n_slabs, const gim_conv_shape* s, void* stream) {
+template <int VEC>
+static void launch_wgrad(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, VEC>), g, dim3(256), 0, st, p);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, VEC>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, VEC>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, VEC>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, VEC>), g, dim3(256), 0, st, p);
+}
+
+extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs,
+                                const gim_conv_shape* s, void* stream) {
     int logH, logW;
     int rc = fill_common(s, &logH, &logW);
     if (rc) return rc;
@@ -480,16 +596,13 @@ extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, i
     wgrad_plan(s, &bm, &bn, &ns, &mper);
     GIM_CHECK_ARG(n_slabs == ns, "conv wgrad: n_slabs must equal gim_conv2d_wgrad_slabs(shape)");
     WgP p;
-    p.dy = dy; p.x = x; p.slabs = slabs;
+    p.dy = dy; p.x = x; p.slabs = slabs; p.bias_slabs = bias_slabs;
     p.N = s->N; p.H = s->H; p.W = s->W; p.logH = logH; p.logW = logW;
     p.Cin = s->Cin; p.Cout = s->Cout; p.KH = s->KH; p.pad = (s->KH - 1) / 2; p.ups = s->ups; p.T = s->KH * s->KH;
     p.M = s->N * s->H * s->W; p.Kcols = p.T * s->Cin; p.mper = mper; p.pre_slope = s->pre_slope;
     dim3 g((p.Kcols + bn - 1) / bn, (s->Cout + bm - 1) / bm, ns);
-    hipStream_t st = (hipStream_t)stream;
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), g, dim3(256), 0, st, p);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1>), g, dim3(256), 0, st, p);
+    const bool vec = (s->Cin % 4 == 0) && (s->Cout % 4 == 0) && !(((uintptr_t)dy | (uintptr_t)x) & 15);
+    if (vec) launch_wgrad<4>(p, bm, bn, g, (hipStream_t)stream);
+    else launch_wgrad<1>(p, bm, bn, g, (hipStream_t)stream);
     return gim_check_launch("gim_conv2d_wgrad");
 }

@@ -121,9 +121,17 @@ extern "C" int gim_spectral_sigma(const float* w, float* u, float* v, float* sig
 
 __global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* __restrict__ slabs, int n_slabs, long long n,
                                                         const float* __restrict__ w, float* __restrict__ dw,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial, const float* __restrict__ bias_slabs,
+                                                        float* __restrict__ db, int Cout) {
     __shared__ float red[4];
     float dot = 0.f;
+    if (db) {
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < Cout; c += gridDim.x * 256) {
+            float g = 0.f;
+            for (int s = 0; s < n_slabs; ++s) g += bias_slabs[(long long)s * Cout + c];
+            db[c] = g;
+        }
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float g = 0.f;
         for (int s = 0; s < n_slabs; ++s) g += slabs[(long long)s * n + i];
@@ -155,9 +163,11 @@ __global__ __launch_bounds__(256) void wgrad_sn_apply_kernel(float* __restrict__
     }
 }
 
-extern "C" int gim_wgrad_finish(const float* slabs, int n_slabs, const float* w, const float* sigma, const float* u,
-                                const float* v, float* dw, float* scratch, int Cout, int Cin, int KH, void* stream) {
+extern "C" int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int n_slabs, const float* w, const float* sigma,
+                                const float* u, const float* v, float* dw, float* db, float* scratch, int Cout, int Cin, int KH,
+                                void* stream) {
     GIM_CHECK_ARG(slabs && dw && n_slabs > 0, "wgrad_finish: bad args");
+    GIM_CHECK_ARG(!db || bias_slabs, "wgrad_finish: db needs bias_slabs");
     GIM_CHECK_ARG(!sigma || (w && u && v && scratch), "wgrad_finish: spectral form needs w, u, v, scratch");
     hipStream_t st = (hipStream_t)stream;
     const int T = KH * KH;
@@ -166,7 +176,7 @@ extern "C" int gim_wgrad_finish(const float* slabs, int n_slabs, const float* w,
     if (blocks > WF_BLOCKS) blocks = WF_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_sum_kernel, dim3(blocks), dim3(256), 0, st, slabs, n_slabs, n, sigma ? w : nullptr, dw,
-                       sigma ? scratch : nullptr);
+                       sigma ? scratch : nullptr, bias_slabs, db, Cout);
     if (sigma)
         hipLaunchKernelGGL(wgrad_sn_apply_kernel, dim3(blocks), dim3(256), 0, st, dw, scratch, blocks, sigma, u, v, n, Cin, T);
     return gim_check_launch("gim_wgrad_finish");

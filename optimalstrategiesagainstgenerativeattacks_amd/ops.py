@@ -112,22 +112,27 @@ class ConvFn(Function):
                 check(lib.gim_upsample2x_bwd(_p(dxu), _p(mask), pre_slope, _p(dx), N, H >> 1, W >> 1, Cin, st), "upsample2x_bwd")
             else:
                 check(lib.gim_conv2d_dgrad(_p(dy), _p(wp), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad")
-        if ctx.needs_input_grad[1]:
+        want_w = ctx.needs_input_grad[1]
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if want_w:
             ns = lib.gim_conv2d_wgrad_slabs(sh)
             if ns <= 0:
                 check(ns, "conv2d_wgrad_slabs")
             K = KH * KH * Cin
             dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
+            if want_b:
+                db = torch.empty(Cout, device=dev, dtype=torch.float32)
             if ns == 1 and sigma is None:
-                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(dwp), 1, sh, st), "conv2d_wgrad")
+                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(dwp), _p(db), 1, sh, st), "conv2d_wgrad")
             else:
                 slabs = torch.empty(ns * Cout * K, device=dev, dtype=torch.float32)
+                bslabs = torch.empty(ns * Cout, device=dev, dtype=torch.float32) if want_b else None
                 scratch = torch.empty(512, device=dev, dtype=torch.float32)
-                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(slabs), ns, sh, st), "conv2d_wgrad")
-                check(lib.gim_wgrad_finish(_p(slabs), ns, _p(wp), _p(sigma), _p(u_s), _p(v_s), _p(dwp), _p(scratch),
-                                           Cout, Cin, KH, st), "wgrad_finish")
+                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(slabs), _p(bslabs), ns, sh, st), "conv2d_wgrad")
+                check(lib.gim_wgrad_finish(_p(slabs), _p(bslabs), ns, _p(wp), _p(sigma), _p(u_s), _p(v_s), _p(dwp), _p(db),
+                                           _p(scratch), Cout, Cin, KH, st), "wgrad_finish")
             dw = dwp.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2) if w.dim() == 4 else dwp.view(Cout, Cin)
-        if has_bias and ctx.needs_input_grad[2]:
+        elif want_b:
             db = torch.empty(Cout, device=dev, dtype=torch.float32)
             scratch = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
             check(lib.gim_colsum(_p(dy), _p(db), _p(scratch), N * H * W, Cout, st), "colsum")

@@ -35,6 +35,10 @@ def _view_like(flat_slice, ref):
     return flat_slice.view(ref.shape)
 
 
+def _pad(n, align=64):
+    return (n + align - 1) // align * align
+
+
 def all_reduce_grads_(flat_g):
     """Data-parallel gradient exchange: ONE all-reduce(sum) of a flat gradient bucket over RCCL/xGMI (gloo in
     the CPU tests).  Each rank's bucket holds the gradient of its local mean loss, so the global-batch
@@ -64,8 +68,10 @@ class FusedAdam(torch.optim.Optimizer):
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FusedAdam runs on the GPU only (parameters are on %s); there is no CPU fallback" % dev)
-        total = sum(p.numel() for p in params)
-        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        # every tensor starts on a 256-byte boundary of the flat buffers: the conv kernels need 16-byte
+        # aligned weights for their vector loads (the padding elements are zeros and stay zeros)
+        total = sum(_pad(p.numel()) for p in params)
+        self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -89,7 +95,7 @@ class FusedAdam(torch.optim.Optimizer):
                         _view_like(self.flat_v[o:o + n], p).copy_(st["exp_avg_sq"])
                         self._host_step = max(self._host_step, int(st["step"]))
                     self._offsets[p] = (o, n)
-                    o += n
+                    o += _pad(n)
                 seg_end.append(o)
         self._seg_end = torch.tensor(seg_end, dtype=torch.int64, device=dev)
         self._lr_dev = torch.zeros(len(seg_end), dtype=torch.float32, device=dev)
