@@ -1,0 +1,105 @@
+"""Per-layer roofline table: record every convolution / linear shape one training iteration launches, then time
+the forward, dgrad and wgrad kernels of each distinct shape through the C ABI with HIP events.
+
+    python tools/conv_shapes_bench.py [--workload vox64] [--batch 16] > gpurun_out/conv_shapes.txt
+"""
+import argparse
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from optimalstrategiesagainstgenerativeattacks_amd import _lib, ops  # noqa: E402
+
+
+def time_ms(fn, reps=5):
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="vox64")
+    ap.add_argument("--batch", type=int, default=16)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    u = bench.UNIT[args.workload]
+    m, n, k, B = 1, 5, 10, args.batch
+    G, tr = bench.build_trainer(u["S"], u["C"], n, m, k, dev)
+    trainer = G.DataParallelMock(tr)
+    leaked, real, si = bench.synthetic_batch(B, m, n, k, u["C"], u["S"], dev, 1234)
+
+    fwd_calls, bwd_calls = collections.Counter(), collections.Counter()
+    orig_f, orig_b = ops.ConvFn.forward, ops.ConvFn.backward
+
+    def rec_f(ctx, *a):
+        y = orig_f(ctx, *a)
+        fwd_calls[ctx.cfg[:8]] += 1
+        return y
+
+    def rec_b(ctx, dy):
+        bwd_calls[(ctx.cfg[:8], bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]))] += 1
+        return orig_b(ctx, dy)
+
+    ops.ConvFn.forward, ops.ConvFn.backward = staticmethod(rec_f), staticmethod(rec_b)
+    G.gim_step(trainer, leaked, real, si)
+    torch.cuda.synchronize()
+    ops.ConvFn.forward, ops.ConvFn.backward = staticmethod(orig_f), staticmethod(orig_b)
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    rows = []
+    tot = collections.Counter()
+    for cfg, cnt in fwd_calls.items():
+        N, H, W, Cin, Cout, KH, ups, slope = cfg
+        n_dx = sum(c for (cf, dx, dw), c in bwd_calls.items() if cf == cfg and dx)
+        n_dw = sum(c for (cf, dx, dw), c in bwd_calls.items() if cf == cfg and dw)
+        sh = _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope)
+        x = torch.randn(N, H >> ups, W >> ups, Cin, device=dev)
+        w = torch.randn(Cout, KH, KH, Cin, device=dev) * 0.05
+        y = torch.randn(N, H, W, Cout, device=dev)
+        dx = torch.empty(N, H, W, Cin, device=dev)
+        ns = lib.gim_conv2d_wgrad_slabs(sh)
+        slabs = torch.empty(ns * Cout * KH * KH * Cin, device=dev)
+        dw = torch.empty(Cout * KH * KH * Cin, device=dev)
+        scr = torch.empty(512, device=dev)
+        flops = 2.0 * N * H * W * Cout * Cin * KH * KH
+        t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
+        t_d = time_ms(lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
+
+        def wg():
+            lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st)
+            lib.gim_wgrad_finish(slabs.data_ptr(), None, ns, None, None, None, None, dw.data_ptr(), None, scr.data_ptr(), Cout, Cin, KH, st)
+        t_w = time_ms(wg) if n_dw else 0.0
+        total = cnt * t_f + n_dx * t_d + n_dw * t_w
+        tot["fwd"] += cnt * t_f
+        tot["dgrad"] += n_dx * t_d
+        tot["wgrad"] += n_dw * t_w
+        tot["gflop"] += flops * (cnt + n_dx + n_dw) / 1e9
+        rows.append((total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns))
+    rows.sort(reverse=True)
+    print("%-46s %4s %4s %4s %8s | %8s %6s | %8s %6s | %8s %6s %4s | %8s" %
+          ("N,H,W,Cin,Cout,K,ups,slope", "fwd", "dx", "dw", "GF", "fwd ms", "TF", "dgrad ms", "TF", "wgrad ms", "TF", "S", "tot ms"))
+    for total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns in rows:
+        tf = lambda t: flops / t / 1e9 if t else 0.0  # noqa: E731
+        print("%-46s %4d %4d %4d %8.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f %4d | %8.2f" %
+              (",".join(str(c) for c in cfg), cnt, n_dx, n_dw, flops / 1e9, t_f, tf(t_f), t_d, tf(t_d), t_w, tf(t_w), ns, total))
+    s = tot["fwd"] + tot["dgrad"] + tot["wgrad"]
+    print("sum of conv/linear kernels per step: %.1f ms (fwd %.1f, dgrad %.1f, wgrad %.1f); executed %.0f GFLOP -> %.1f TFLOP/s"
+          % (s, tot["fwd"], tot["dgrad"], tot["wgrad"], tot["gflop"], tot["gflop"] / s))
+
+
+if __name__ == "__main__":
+    main()
