@@ -139,10 +139,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # rehearsal knobs for a 1-GPU box: GIM_BENCH_BACKEND=gloo GIM_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0
+    backend = os.environ.get("GIM_BENCH_BACKEND", "nccl")
+    if os.environ.get("GIM_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     m, n, k = 1, 5, 10
     u = UNIT[args.workload]

@@ -80,6 +80,21 @@ int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int n_slabs, c
 int gim_spectral_sigma(const float* w, float* u, float* v, float* sigma, float* u_out, float* v_out, float* scratch,
                        int Cout, int Cin, int KH, int training, void* stream);
 
+/* The same power iteration for ALL spectral-normed convs of a model in one call (4 launches per round instead
+ * of 4 per conv call; the iterations do not depend on activations).  jobs / tab_cols / tab_rows are DEVICE arrays,
+ * static per model:  tab_cols[i] = {job, 256-column block, row chunk r, rows per chunk} for every
+ * (job, block, r < min(8, ceil(Cout/64))),  tab_rows[i] = {job, 4-row block}.  Results of job j land at
+ * out_base + off_sigma (1 float), + off_u (Cout), + off_v (Cin*KH*KH); off_scratch needs 10*Cin*KH*KH + Cout floats. */
+typedef struct {
+    const float* w;
+    float* u;
+    float* v;
+    int64_t off_sigma, off_u, off_v, off_scratch;
+    int32_t Cout, Cin, KH, reserved;
+} gim_sn_job;
+int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, const int32_t* tab_cols, int n_col_blocks,
+                               const int32_t* tab_rows, int n_row_blocks, float* out_base, int training, void* stream);
+
 /* Column sums: out[c] = sum_r x[r][c]  (bias gradients; rows x C). scratch >= 256*C floats. */
 int gim_colsum(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream);
 

@@ -28,6 +28,7 @@ SIGNATURES = {
     "gim_conv2d_wgrad": [P, P, P, P, c_int, SP, P],
     "gim_wgrad_finish": [P, P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, P],
     "gim_spectral_sigma": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "gim_spectral_sigma_batched": [P, c_int, P, c_int, P, c_int, P, c_int, P],
     "gim_colsum": [P, P, P, c_int64, c_int, P],
     "gim_norm_fwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "gim_norm_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],

@@ -34,6 +34,8 @@ struct ConvP {
     int M;
     int Ktot;
     float pre_slope, mask_slope;
+    int ksplit;   // > 1: grid.z K-slices, partial results combined with float atomics into a pre-zeroed y
+    int kper;     // K-steps per slice
 };
 
 // GENF bit 0: generic K (channel count of the gathered tensor not a multiple of 16, or unaligned base)
@@ -223,11 +225,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (p.Ktot + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
+    const int nk_all = (p.Ktot + BK - 1) / BK;
+    const int ks0 = blockIdx.z * p.kper;
+    const int nk = min(nk_all, ks0 + p.kper);
+    load_tiles(ks0 * BK);
+    store_tiles(ks0 & 1);
     __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
+    for (int ks = ks0; ks < nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nk) load_tiles((ks + 1) * BK);
         const float* Ab = As + buf * A_SZ;
@@ -266,16 +270,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         for (int j = 0; j < TN; ++j) {
             const int co = n0 + wn0 + 32 * j + r;
             if (co >= p.Cb) continue;
-            const float bv = p.bias ? p.bias[co] : 0.f;
+            const bool first = blockIdx.z == 0;
+            const float bv = (p.bias && first) ? p.bias[co] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m >= p.M) continue;
                 const long long o = (long long)m * p.Cb + co;
                 float v = acc[i][j][e] * inv_sigma + bv;
-                if (p.res) v += p.res[o];
+                if (p.res && first) v += p.res[o];
                 if (p.mask_x) v *= (p.mask_x[o] > 0.f ? 1.0f : p.mask_slope);
-                p.y[o] = v;
+                if (p.ksplit > 1) atomicAdd(&p.y[o], v);
+                else p.y[o] = v;
             }
         }
 }
@@ -478,36 +484,40 @@ static int fill_common(const gim_conv_shape* s, int* logH, int* logW) {
     return GIM_OK;
 }
 
+// Small-M layers (4x4x512 maps, the decoder head, linears on <= 240 rows) have too few output tiles to fill
+// 256 CUs and are bound by the latency of their long K loop: slice K over grid.z until there are ~2 workgroups
+// per CU, each keeping >= 8 K-steps.
+static int plan_ksplit(long long wgs, int nk) {
+    if (wgs >= 192 || nk < 16) return 1;
+    long long ks = (256 + wgs - 1) / wgs;
+    if (ks > nk / 8) ks = nk / 8;
+    if (ks > 32) ks = 32;
+    return ks < 1 ? 1 : (int)ks;
+}
+
+template <int BM, int BN, int TM, int TN, int BMODE, int GEN>
+static void launch_cfg(ConvP p, hipStream_t st) {
+    const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
+    const int nk = (p.Ktot + BK - 1) / BK;
+    p.ksplit = plan_ksplit((long long)gx * gy, nk);
+    p.kper = (nk + p.ksplit - 1) / p.ksplit;
+    p.ksplit = (nk + p.kper - 1) / p.kper;
+    if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, (size_t)p.M * p.Cb * sizeof(float), st);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN>), dim3(gx, gy, p.ksplit), dim3(256), 0, st, p);
+}
+
 template <int BMODE, int GEN>
 static void launch_igemm(const ConvP& p, hipStream_t st) {
+    // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K
     const int M = p.M, Cb = p.Cb;
     if (Cb > 64) {
-        // fill the 256 CUs: drop to 64-row tiles when 128-row tiles would leave most of them idle
-        const long long wg128 = (long long)((M + 127) / 128) * ((Cb + 127) / 128);
-        if (wg128 >= 256 || M <= 64) {
-            if (M <= 64) {
-                dim3 g((M + 63) / 64, (Cb + 127) / 128);
-                hipLaunchKernelGGL((conv_igemm_kernel<64, 128, 1, 2, BMODE, GEN>), g, dim3(256), 0, st, p);
-            } else {
-                dim3 g((M + 127) / 128, (Cb + 127) / 128);
-                hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, BMODE, GEN>), g, dim3(256), 0, st, p);
-            }
-        } else {
-            dim3 g((M + 63) / 64, (Cb + 63) / 64);
-            hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 1, 1, BMODE, GEN>), g, dim3(256), 0, st, p);
-        }
+        if (M <= 64) launch_cfg<64, 128, 1, 2, BMODE, GEN>(p, st);
+        else launch_cfg<128, 128, 2, 2, BMODE, GEN>(p, st);
     } else if (Cb > 32) {
-        const long long wg128 = (long long)((M + 127) / 128);
-        if (wg128 >= 256) {
-            dim3 g((M + 127) / 128, 1);
-            hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 1, BMODE, GEN>), g, dim3(256), 0, st, p);
-        } else {
-            dim3 g((M + 63) / 64, 1);
-            hipLaunchKernelGGL((conv_igemm_kernel<64, 64, 1, 1, BMODE, GEN>), g, dim3(256), 0, st, p);
-        }
+        if (M <= 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, st);
+        else launch_cfg<128, 64, 2, 1, BMODE, GEN>(p, st);
     } else {
-        dim3 g((M + 127) / 128, 1);
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 1, 1, BMODE, GEN>), g, dim3(256), 0, st, p);
+        launch_cfg<128, 32, 1, 1, BMODE, GEN>(p, st);
     }
 }
 

@@ -181,3 +181,115 @@ extern "C" int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int
         hipLaunchKernelGGL(wgrad_sn_apply_kernel, dim3(blocks), dim3(256), 0, st, dw, scratch, blocks, sigma, u, v, n, Cin, T);
     return gim_check_launch("gim_wgrad_finish");
 }
+
+// -------------------------------------------------------------------------------------------------
+// batched power iteration: ONE round (one iteration of every conv of a model) in 4 launches.
+// The iterations are data independent, so a model runs all its rounds up front instead of 4 tiny launches
+// per conv call.  Job table and block->job maps are static per model; per-round outputs live at static
+// offsets from `out_base`.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void snb_colpart_kernel(const gim_sn_job* __restrict__ jobs, const int4* __restrict__ tab,
+                                                          float* __restrict__ out_base) {
+    const int4 e = tab[blockIdx.x];  // {job, column block, row chunk, rows per chunk}
+    const gim_sn_job jb = jobs[e.x];
+    const int K = jb.Cin * jb.KH * jb.KH;
+    const int p = e.y * 256 + threadIdx.x;
+    if (p >= K) return;
+    const int c0 = e.z * e.w, c1 = min(jb.Cout, c0 + e.w);
+    float acc = 0.f;
+    for (int co = c0; co < c1; ++co) acc += jb.w[(long long)co * K + p] * jb.u[co];
+    (out_base + jb.off_scratch)[(long long)e.z * K + p] = acc;
+}
+
+__global__ __launch_bounds__(256) void snb_vnorm_kernel(const gim_sn_job* __restrict__ jobs, float* __restrict__ out_base, int training) {
+    __shared__ float red[4];
+    const gim_sn_job jb = jobs[blockIdx.x];
+    const int T = jb.KH * jb.KH, K = jb.Cin * T;
+    const int R = min(SN_R, (jb.Cout + 63) / 64);
+    float* part = out_base + jb.off_scratch;
+    float* v_phys = part + (long long)SN_R * K;
+    float* v_out = out_base + jb.off_v;
+    if (training) {
+        float ss = 0.f;
+        for (int p = threadIdx.x; p < K; p += 256) {
+            float a = 0.f;
+            for (int r = 0; r < R; ++r) a += part[(long long)r * K + p];
+            v_phys[p] = a;
+            ss += a * a;
+        }
+        const float inv = 1.0f / fmaxf(sqrtf(block_sum_256(ss, red)), 1e-12f);
+        for (int p = threadIdx.x; p < K; p += 256) {
+            const float val = v_phys[p] * inv;
+            const int tap = p / jb.Cin, ci = p - tap * jb.Cin;
+            const int q = ci * T + tap;
+            v_phys[p] = val;
+            jb.v[q] = val;
+            v_out[q] = val;
+        }
+    } else {
+        for (int q = threadIdx.x; q < K; q += 256) {
+            const int ci = q / T, tap = q - ci * T;
+            const float val = jb.v[q];
+            v_phys[tap * jb.Cin + ci] = val;
+            v_out[q] = val;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void snb_rowdot_kernel(const gim_sn_job* __restrict__ jobs, const int2* __restrict__ tab,
+                                                         float* __restrict__ out_base) {
+    const int2 e = tab[blockIdx.x];  // {job, row block}
+    const gim_sn_job jb = jobs[e.x];
+    const int K = jb.Cin * jb.KH * jb.KH;
+    const int co = e.y * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (co >= jb.Cout) return;
+    const float* v_phys = out_base + jb.off_scratch + (long long)SN_R * K;
+    float* tvec = out_base + jb.off_scratch + (long long)(SN_R + 1) * K;
+    const float* row = jb.w + (long long)co * K;
+    float acc = 0.f;
+    for (int p = lane; p < K; p += 64) acc += row[p] * v_phys[p];
+    acc = wave_sum(acc);
+    if (lane == 0) tvec[co] = acc;
+}
+
+__global__ __launch_bounds__(256) void snb_final_kernel(const gim_sn_job* __restrict__ jobs, float* __restrict__ out_base, int training) {
+    __shared__ float red[4];
+    const gim_sn_job jb = jobs[blockIdx.x];
+    const int K = jb.Cin * jb.KH * jb.KH;
+    const float* tvec = out_base + jb.off_scratch + (long long)(SN_R + 1) * K;
+    float* u_out = out_base + jb.off_u;
+    float inv = 0.f;
+    if (training) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < jb.Cout; c += 256) ss += tvec[c] * tvec[c];
+        inv = 1.0f / fmaxf(sqrtf(block_sum_256(ss, red)), 1e-12f);
+    }
+    float dot = 0.f;
+    for (int c = threadIdx.x; c < jb.Cout; c += 256) {
+        float uv;
+        if (training) {
+            uv = tvec[c] * inv;
+            jb.u[c] = uv;
+        } else {
+            uv = jb.u[c];
+        }
+        u_out[c] = uv;
+        dot += uv * tvec[c];
+    }
+    dot = block_sum_256(dot, red);
+    if (threadIdx.x == 0) (out_base + jb.off_sigma)[0] = dot;
+}
+
+extern "C" int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, const int32_t* tab_cols, int n_col_blocks,
+                                          const int32_t* tab_rows, int n_row_blocks, float* out_base, int training, void* stream) {
+    GIM_CHECK_ARG(jobs && n_jobs > 0 && tab_cols && tab_rows && out_base && n_col_blocks > 0 && n_row_blocks > 0,
+                  "spectral_sigma_batched: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (training)
+        hipLaunchKernelGGL(snb_colpart_kernel, dim3(n_col_blocks), dim3(256), 0, st, jobs, reinterpret_cast<const int4*>(tab_cols), out_base);
+    hipLaunchKernelGGL(snb_vnorm_kernel, dim3(n_jobs), dim3(256), 0, st, jobs, out_base, training);
+    hipLaunchKernelGGL(snb_rowdot_kernel, dim3(n_row_blocks), dim3(256), 0, st, jobs, reinterpret_cast<const int2*>(tab_rows), out_base);
+    hipLaunchKernelGGL(snb_final_kernel, dim3(n_jobs), dim3(256), 0, st, jobs, out_base, training);
+    return gim_check_launch("gim_spectral_sigma_batched");
+}

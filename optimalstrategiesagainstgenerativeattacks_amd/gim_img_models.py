@@ -201,8 +201,16 @@ class GIMFaceAuthenticator(nn.Module):
         self.src_encoder = src_encoder
         self.env_encoder = env_encoder
         self.dis = dis
+        self._sn_plan = None
+
+    def prefetch_spectral(self, rounds):
+        """Run the power iterations of the next `rounds` calls of each encoder up front (mb.SNPlan)."""
+        if self._sn_plan is None:
+            self._sn_plan = mb.SNPlan(mb.sn_convs(self.src_encoder, self.env_encoder))
+        self._sn_plan.run(rounds, self.training)
 
     def forward(self, test_sample, si_sample):
+        self.prefetch_spectral(2)
         test_src = self.src_encode_sample(test_sample)
         si_src = self.src_encode_sample(si_sample)
         test_env = self.env_encode_sample(test_sample)
@@ -230,10 +238,14 @@ class GIMFaceImpersonator(nn.Module):
         assert src_encoder.style_dim == env_encoder.style_dim == env_decoder.style_dim == img2img.style_dim
         self.use_img_att = use_img_att
         self.img_att = mb.ImgAttention(img1_channels=self.src_encoder.img_channels, img2_channels=self.img2img.out_channels)
+        self._sn_plan = None
 
     def forward(self, leaked_sample, n, remove_noise_mean=True, z=None):
         if self.use_img_att:
             raise NotImplementedError("use_img_att=True is not on the accelerated hot path yet")
+        if self._sn_plan is None:
+            self._sn_plan = mb.SNPlan(mb.sn_convs(self.src_encoder, self.env_encoder, self.env_decoder, self.img2img))
+        self._sn_plan.run(1, self.training)
         B, m, C, S, _ = leaked_sample.size()
         leaked = ops.to_nhwc(leaked_sample.reshape(B * m, C, S, S))
         src = ops.mean_dim1(self.src_encoder(leaked).view(B, m, -1))

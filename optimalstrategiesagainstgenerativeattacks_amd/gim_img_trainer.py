@@ -93,6 +93,7 @@ class GIMImgTrainer(nn.Module):
         if grad and self.reg_param > 0:
             raise NotImplementedError("reg_param > 0 (R1 double backward) is not on the accelerated path yet; use reg_param=0")
 
+        self.authenticator.prefetch_spectral(3)  # si, real, fake: three calls of each encoder
         au_si_src = self.authenticator.src_encode_sample(si_sample)
         au_si_env = self.authenticator.env_encode_sample(si_sample)
         au_real_src = self.authenticator.src_encode_sample(real_sample)

@@ -13,11 +13,14 @@ convolution fused into it:
 
 Unless noted, tensors between blocks are NHWC ``[N, H, W, C]`` float32 on the GPU.
 """
+import collections
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import ops
 
 LRELU = 0.2
@@ -104,12 +107,92 @@ class SNConv2d(nn.Module):
         self.register_buffer("weight_u", u)
         self.register_buffer("weight_v", v)
 
+        self._sn_queue = collections.deque()  # (sigma, u, v) triples precomputed by an SNPlan round
+
     def forward(self, x, res=None, ups=0, pre_slope=1.0):
-        sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
+        if self._sn_queue:
+            sigma, u_s, v_s = self._sn_queue.popleft()
+        else:
+            sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
         return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d (spectral norm)" % (self.in_channels, self.out_channels, self.kernel_size)
+
+
+class SNPlan:
+    """Runs the spectral-norm power iterations of MANY convs ahead of their use: the iterations depend on the
+    weights and on u only, never on activations, so a forward pass that will call each conv `rounds` times runs
+    `rounds` batched rounds up front (4 launches each, gim_spectral_sigma_batched) and every SNConv2d call then
+    just pops its precomputed (sigma, u, v).  Sequential semantics are those of the per-call hook: round r uses
+    the u left by round r-1.  The job table is static and rebuilt only if a tensor moves."""
+
+    _JOB = np.dtype([("w", "<u8"), ("u", "<u8"), ("v", "<u8"), ("off_sigma", "<i8"), ("off_u", "<i8"), ("off_v", "<i8"),
+                     ("off_scratch", "<i8"), ("Cout", "<i4"), ("Cin", "<i4"), ("KH", "<i4"), ("reserved", "<i4")])
+
+    def __init__(self, convs):
+        self.convs = [c for c in convs if isinstance(c, SNConv2d)]
+        self._key = None
+
+    def _build(self, key):
+        dev = self.convs[0].weight_orig.device
+        jobs = np.zeros(len(self.convs), dtype=self._JOB)
+        cols, rows, self._views = [], [], []
+        off = 0
+
+        def take(n):
+            nonlocal off
+            o = off
+            off += (n + 3) // 4 * 4
+            return o
+        for j, c in enumerate(self.convs):
+            Cout, Cin, KH = c.out_channels, c.in_channels, c.kernel_size
+            K = Cin * KH * KH
+            if not c.weight_orig.permute(0, 2, 3, 1).is_contiguous():
+                raise RuntimeError("SNPlan: weight_orig must be stored channels-last")
+            o_s, o_u, o_v, o_scr = take(1), take(Cout), take(K), take(10 * K + Cout)
+            jobs[j] = (c.weight_orig.data_ptr(), c.weight_u.data_ptr(), c.weight_v.data_ptr(), o_s, o_u, o_v, o_scr, Cout, Cin, KH, 0)
+            R = min(8, (Cout + 63) // 64)
+            rows_per = (Cout + R - 1) // R
+            for xb in range((K + 255) // 256):
+                for r in range(R):
+                    cols.append((j, xb, r, rows_per))
+            for rb in range((Cout + 3) // 4):
+                rows.append((j, rb))
+            self._views.append((o_s, o_u, Cout, o_v, K))
+        self._total = off
+        self._jobs = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+        self._cols = torch.tensor(cols, dtype=torch.int32).to(dev)
+        self._rows = torch.tensor(rows, dtype=torch.int32).to(dev)
+        self._n = (len(self.convs), len(cols), len(rows))
+        self._key = key
+
+    @torch.no_grad()
+    def run(self, rounds, training):
+        if not self.convs:
+            return
+        w0 = self.convs[0].weight_orig
+        if not (w0.is_cuda and w0.dtype == torch.float32):
+            raise RuntimeError("weights must be CUDA float32 (got %s on %s): the GIM engine has no CPU path" % (w0.dtype, w0.device))
+        key = tuple(t.data_ptr() for c in self.convs for t in (c.weight_orig, c.weight_u, c.weight_v))
+        if key != self._key:
+            self._build(key)
+        lib = _lib.load()
+        dev = self.convs[0].weight_orig.device
+        for c in self.convs:
+            c._sn_queue.clear()
+        for _ in range(rounds):
+            out = torch.empty(self._total, device=dev, dtype=torch.float32)
+            _lib.check(lib.gim_spectral_sigma_batched(self._jobs.data_ptr(), self._n[0], self._cols.data_ptr(), self._n[1],
+                                                      self._rows.data_ptr(), self._n[2], out.data_ptr(), 1 if training else 0,
+                                                      torch.cuda.current_stream().cuda_stream), "spectral_sigma_batched")
+            for c, (o_s, o_u, Cout, o_v, K) in zip(self.convs, self._views):
+                c._sn_queue.append((out[o_s:o_s + 1], out[o_u:o_u + Cout], out[o_v:o_v + K]))
+
+
+def sn_convs(*modules):
+    """All SNConv2d sub-modules of the given modules, in registration order."""
+    return [m for mod in modules for m in mod.modules() if isinstance(m, SNConv2d)]
 
 
 class GimInstanceNorm2d(nn.Module):
