@@ -14,10 +14,11 @@
 // k+1 are in flight under the MFMAs of step k; one barrier per K step.
 // k-contiguous LDS rows are padded 16 -> 20 floats: every 16-lane group of a ds_read_b128 then
 // touches 16 distinct 16-byte bank slots (conflict-free, MI355X_MICROARCH LDS table).
+#include <stdlib.h>
+
 #include "common.h"
 
-#define BK 16
-#define LDK 20
+#define BK 16  // wgrad pixel step; also the K granularity the fast paths require (channels % 16 == 0)
 
 struct ConvP {
     const float* x;
@@ -40,21 +41,24 @@ struct ConvP {
 
 // GENF bit 0: generic K (channel count of the gathered tensor not a multiple of 16, or unaligned base)
 // GENF bit 1: (BMODE 1 only) scalar loads of the k-major weight tile (output channels not a multiple of 4)
-template <int BM, int BN, int TM, int TN, int BMODE, int GENF>
+template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
     constexpr bool BSCALAR = (GENF & 2) != 0;
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    constexpr int A_ROWS = BM / 64;
-    constexpr int B_ROWS = (BN + 63) / 64;         // BMODE 0
-    constexpr int B_PER = BK * BN / 256;           // BMODE 1, scalar
+    constexpr int LDK = KB + 4;                    // padded k-row (conflict-free ds_read_b128 for KB = 16 and 32)
+    constexpr int QPR = KB / 4;                    // float4 per k-row
+    constexpr int RP = 256 / QPR;                  // tile rows filled per pass
+    constexpr int A_ROWS = BM / RP;
+    constexpr int B_ROWS = (BN + RP - 1) / RP;     // BMODE 0
+    constexpr int B_PER = KB * BN / 256;           // BMODE 1, scalar
     constexpr int B_U = BN / 4;                    // BMODE 1, vector: float4 units per k-row
     constexpr int B_RSTEP = 256 / B_U;
-    constexpr int B_PER4 = (BK + B_RSTEP - 1) / B_RSTEP;
+    constexpr int B_PER4 = (KB + B_RSTEP - 1) / B_RSTEP;
     constexpr int A_SZ = BM * LDK;
-    constexpr int B_SZ = (BMODE == 0) ? BN * LDK : BK * BN;
+    constexpr int B_SZ = (BMODE == 0) ? BN * LDK : KB * BN;
     __shared__ __attribute__((aligned(16))) float lds[2 * A_SZ + 2 * B_SZ];
     float* As = lds;
     float* Bs = lds + 2 * A_SZ;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     const int t = threadIdx.x;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int arow = t >> 2, aq = (t & 3) * 4;
+    const int arow = t / QPR, aq = (t % QPR) * 4;
     const int Hs = p.H >> p.ups, Ws = p.W >> p.ups;
 
     int a_oh[A_ROWS], a_ow[A_ROWS];
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     bool a_ok[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        const int m = m0 + arow + 64 * i;
+        const int m = m0 + arow + RP * i;
         a_ok[i] = m < p.M;
         const int n = m >> (p.logH + p.logW);
         a_oh[i] = (m >> p.logW) & (p.H - 1);
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         if constexpr (BMODE == 0) {
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) {
-                const int row = arow + 64 * i;
+                const int row = arow + RP * i;
                 const int co = n0 + row;
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (row < BN && co < p.Cb) {
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 for (int i = 0; i < B_PER4; ++i) {
                     const int krow = t / B_U + i * B_RSTEP, col = (t % B_U) * 4;
                     int tap, ca;
-                    bool v = krow < BK;
+                    bool v = krow < KB;
                     if constexpr (!GEN) {
                         tap = tap_u;
                         ca = c0_u + krow;
@@ -193,11 +197,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i)
-            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + 64 * i) * LDK + aq]) = ra[i];
+            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
         if constexpr (BMODE == 0) {
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) {
-                const int row = arow + 64 * i;
+                const int row = arow + RP * i;
                 if (row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
             }
         } else {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
                 for (int i = 0; i < B_PER4; ++i) {
                     const int krow = t / B_U + i * B_RSTEP, col = (t % B_U) * 4;
-                    if (krow < BK) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + krow * BN + col]) = rb4[i];
+                    if (krow < KB) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + krow * BN + col]) = rb4[i];
                 }
             }
         }
@@ -225,19 +229,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk_all = (p.Ktot + BK - 1) / BK;
+    const int nk_all = (p.Ktot + KB - 1) / KB;
     const int ks0 = blockIdx.z * p.kper;
     const int nk = min(nk_all, ks0 + p.kper);
-    load_tiles(ks0 * BK);
+    load_tiles(ks0 * KB);
     store_tiles(ks0 & 1);
     __syncthreads();
     for (int ks = ks0; ks < nk; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) load_tiles((ks + 1) * BK);
+        if (ks + 1 < nk) load_tiles((ks + 1) * KB);
         const float* Ab = As + buf * A_SZ;
         const float* Bb = Bs + buf * B_SZ;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KB / 8; ++kk) {
             f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + 32 * i + r) * LDK + 8 * kk + 4 * h]);
@@ -484,6 +488,10 @@ static int fill_common(const gim_conv_shape* s, int* logH, int* logW) {
     return GIM_OK;
 }
 
+// K step 32 measured SLOWER on MI355X (104 vs 111 episodes/s: 73 KB of LDS per workgroup leaves 2 waves per
+// SIMD instead of 3); kept as an opt-in for A/B runs.
+static const bool g_force_kb16 = getenv("GIM_CONV_KB32") == nullptr;
+
 // Small-M layers (4x4x512 maps, the decoder head, linears on <= 240 rows) have too few output tiles to fill
 // 256 CUs and are bound by the latency of their long K loop: slice K over grid.z until there are ~2 workgroups
 // per CU, each keeping >= 8 K-steps.
@@ -495,15 +503,28 @@ static int plan_ksplit(long long wgs, int nk) {
     return ks < 1 ? 1 : (int)ks;
 }
 
-template <int BM, int BN, int TM, int TN, int BMODE, int GEN>
-static void launch_cfg(ConvP p, hipStream_t st) {
+template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int KB>
+static void launch_cfg_kb(ConvP p, hipStream_t st) {
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
-    const int nk = (p.Ktot + BK - 1) / BK;
+    const int nk = (p.Ktot + KB - 1) / KB;
     p.ksplit = plan_ksplit((long long)gx * gy, nk);
     p.kper = (nk + p.ksplit - 1) / p.ksplit;
     p.ksplit = (nk + p.kper - 1) / p.kper;
     if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, (size_t)p.M * p.Cb * sizeof(float), st);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN>), dim3(gx, gy, p.ksplit), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB>), dim3(gx, gy, p.ksplit), dim3(256), 0, st, p);
+}
+
+// K step 32 halves the barriers and LDS round trips per FLOP; it needs the gathered channel count to be a
+// multiple of 32 (and the vector paths); the large 128-row tiles are the ones that profit.
+template <int BM, int BN, int TM, int TN, int BMODE, int GEN>
+static void launch_cfg(const ConvP& p, hipStream_t st) {
+    if constexpr ((GEN & 1) == 0 && BM == 128) {
+        if (p.Ca % 32 == 0 && !g_force_kb16) {
+            launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 32>(p, st);
+            return;
+        }
+    }
+    launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 16>(p, st);
 }
 
 template <int BMODE, int GEN>
