@@ -34,11 +34,22 @@ int gim_version(void);
 
 /* Shape of one stride-1 'same' convolution (KH x KH, pad = (KH-1)/2) with the fused prologue
  * x~ = nearest_up2^ups( leaky_relu(x, pre_slope) ); pre_slope = 1 disables the activation.
- * H, W are the OUTPUT spatial size; the stored input is [N][H>>ups][W>>ups][Cin]. */
+ * H, W are the CONVOLUTION's spatial size (= size of x~); the stored input is [N][H>>ups][W>>ups][Cin].
+ *   pool    = 1: the output is avgpool2(conv) ([N][H/2][W/2][Cout]; nn.AvgPool2d(2), models/model_blocks.py:502,509),
+ *                computed as ONE stride-2 convolution with the (KH+1)^2-tap folded weights (16/36 of the FLOPs
+ *                for KH = 3, 100/324 for KH = 9).  Needs ups = 0 and wfold = 1.
+ *   wfold   = 1: `w` points to the folded weights F of gim_conv2d_fold_weights ([Cout][KH+1][KH+1][Cin]).  With
+ *                ups = 1 the convolution of the upsampled image is computed in its sub-pixel form (4 output-parity
+ *                classes, ((KH+1)/2)^2 taps each on the LOW-resolution x): same FLOP ratios as above.
+ *   res_ups = 1: (forward) the residual is stored at half resolution and nearest-upsampled on the fly. */
 typedef struct {
     int32_t N, H, W, Cin, Cout, KH, ups;
     float pre_slope;
+    int32_t pool, wfold, res_ups;
 } gim_conv_shape;
+
+/* F[co][a][b][ci] = sum_{dh,dw in {0,1}} w[co][a-dh][b-dw][ci], a, b in [0, KH]  (out-of-range taps are zero). */
+int gim_conv2d_fold_weights(const float* w, float* f, int Cout, int Cin, int KH, void* stream);
 
 /* y = conv(x~, w) / sigma + bias + residual.
  * Replaces F.conv2d behind nn.Conv2d + spectral_norm (models/model_blocks.py:492-495,522-526,744-750,
@@ -48,29 +59,34 @@ typedef struct {
 int gim_conv2d_fwd(const float* x, const float* w, const float* bias, const float* sigma, const float* residual,
                    float* y, const gim_conv_shape* s, void* stream);
 
-/* dx~ = conv_transpose(dy, w) / sigma, at the OUTPUT resolution [N,H,W,Cin] (autograd of the call sites
- * above w.r.t. the input).  If mask_x != NULL (only legal for ups == 0) the result is multiplied by
- * leaky_relu'(mask_x) with slope pre_slope, i.e. it is the gradient w.r.t. the raw input x.
- * For ups == 1 follow with gim_upsample2x_bwd. */
+/* dx~ = conv_transpose(dy, w) / sigma (autograd of the call sites above w.r.t. the input).
+ *   plain / pool : dx is [N,H,W,Cin] (dy is [N,H,W,Cout], or [N,H/2,W/2,Cout] with pool = 1);
+ *   ups without wfold: dx is at the upsampled resolution [N,H,W,Cin]; follow with gim_upsample2x_bwd;
+ *   ups with wfold   : dx is the gradient of the LOW-resolution input [N,H/2,W/2,Cin] directly.
+ * If mask_x != NULL (same shape as dx; not for ups without wfold) the result is multiplied by
+ * leaky_relu'(mask_x) with slope pre_slope, i.e. it is the gradient w.r.t. the raw input x. */
 int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
                      const gim_conv_shape* s, void* stream);
 
-/* Split-K weight gradient: slabs[i] ([Cout][KH][KW][Cin] each) for i < n_slabs hold partial sums over
- * disjoint pixel ranges of  dy^T * im2col(x~);  bias_slabs[i] ([Cout] each, may be NULL) the matching partial
+/* Split-K weight gradient: slabs[i] for i < n_slabs hold partial sums over disjoint pixel ranges of
+ * dy^T * im2col(x~): layout [Cout][KH][KW][Cin] (plain), [Cout][KH+1][KH+1][Cin] (pool: gradient of F) or
+ * [Cin][KH+1][KH+1][Cout] (ups + wfold: transposed gradient of F; no bias_slabs in this form);  bias_slabs[i] ([Cout] each, may be NULL) the matching partial
  * sums of dy over pixels (the bias gradient, produced from the dy tiles the kernel streams anyway).
  * n_slabs from gim_conv2d_wgrad_slabs(). */
 int gim_conv2d_wgrad_slabs(const gim_conv_shape* s);
 int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs, const gim_conv_shape* s,
                      void* stream);
 
-/* Finish a weight gradient: g = sum_i slabs[i]; db = sum_i bias_slabs[i] (if db != NULL);
+/* Finish a weight gradient: g = sum_i slabs[i] (un-folded to [Cout][KH][KW][Cin] when fold != 0: fold = 1 for
+ * pool slabs, 2 for ups + wfold slabs); db = sum_i bias_slabs[i] (if db != NULL);
  *   sigma == NULL : dw = g                                   (plain nn.Linear weight)
  *   else          : dw = g / sigma - (<g, w> / sigma^2) u v^T (autograd through torch spectral_norm's
  *                   weight = weight_orig / (u^T W v) with u, v constants).
- * u [Cout]; v [Cin*KH*KW] in the REFERENCE's flattening order (ci, kh, kw).  scratch: >= 512 floats. */
+ * u [Cout]; v [Cin*KH*KW] in the REFERENCE's flattening order (ci, kh, kw).  scratch: >= 512 floats, plus
+ * Cout*(KH+1)^2*Cin floats when fold != 0. */
 int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int n_slabs, const float* w, const float* sigma,
                      const float* u, const float* v, float* dw, float* db, float* scratch, int Cout, int Cin, int KH,
-                     void* stream);
+                     int fold, void* stream);
 
 /* One power iteration of torch.nn.utils.spectral_norm (n_power_iterations=1, eps=1e-12, dim=0):
  *   v <- normalize(W^T u); u <- normalize(W v); sigma = u^T W v.       (training = 1)

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgim_hip.so")
 
 class GimConvShape(ctypes.Structure):
     _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
-                ("KH", c_int32), ("ups", c_int32), ("pre_slope", c_float)]
+                ("KH", c_int32), ("ups", c_int32), ("pre_slope", c_float),
+                ("pool", c_int32), ("wfold", c_int32), ("res_ups", c_int32)]
 
 
 P = c_void_p
@@ -26,7 +27,8 @@ SIGNATURES = {
     "gim_conv2d_dgrad": [P, P, P, P, P, SP, P],
     "gim_conv2d_wgrad_slabs": [SP],
     "gim_conv2d_wgrad": [P, P, P, P, c_int, SP, P],
-    "gim_wgrad_finish": [P, P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "gim_wgrad_finish": [P, P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "gim_conv2d_fold_weights": [P, P, c_int, c_int, c_int, P],
     "gim_spectral_sigma": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_spectral_sigma_batched": [P, c_int, P, c_int, P, c_int, P, c_int, P],
     "gim_colsum": [P, P, P, c_int64, c_int, P],

@@ -1,13 +1,23 @@
 // fp32 implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), NHWC.
 //
 //   forward / dgrad :  Y[m][n] = sum_k A[m][k] * B[k][n]
-//        m = output pixel (n_img, oh, ow), k = (tap, channel of the gathered tensor), n = output channel
+//        m = output pixel (n_img, oy, ox), k = (tap, channel of the gathered tensor), n = output channel
 //        A is gathered on the fly from the NHWC activation (im2col never materialised); the gather
 //        applies the fused prologue  nearest-up2( leaky_relu(x) )  and zero padding.
-//        B comes straight from the weight tensor [Cout][KH][KW][Cin]:
+//        B comes straight from the weight tensor [Cout][KF][KF][Cin]:
 //          forward: k-contiguous rows  (BMODE 0, LDS image [n][k], operands by ds_read_b128)
-//          dgrad  : the same tensor read "k-major" with the taps flipped (BMODE 1, LDS image [k][n])
+//          dgrad  : the same tensor read "k-major" with the taps re-mapped (BMODE 1, LDS image [k][n])
 //   wgrad : C[co][j] = sum_m dY[m][co] * A[m][j],  j = (tap, ci), split over pixel slices into slabs.
+//
+// One gather/output geometry (struct Geo) covers four families, so that pooling and upsampling never cost
+// convolution FLOPs (FOLDS):
+//   plain      : iy = oy + ta - pad
+//   S2         : iy = 2*oy + ta - pad over the (K+1)^2-tap folded weights F = sum of 2x2-shifted copies of W
+//                = avgpool2(conv_KxK(x)) forward [16/36 of the FLOPs for K=3, 100/324 for K=9], and the dgrad
+//                and wgrad of the sub-pixel form below
+//   PC kind 0  : the 4 output-parity classes of conv_KxK(nearest_up2(x)): each class is a ((K+1)/2)^2-tap
+//                convolution of the LOW-resolution x with a strided subset of F's taps
+//   PC kind 1  : the 4 input-parity classes of the dgrad of S2
 //
 // Tiles: 256 threads = 4 waves, each wave owns a (32*TM) x (32*TN) block of 32x32 MFMA accumulators;
 // K step 16; LDS double-buffered, register-staged (global -> VGPR -> LDS) so that the loads of step
@@ -20,7 +30,45 @@
 
 #define BK 16  // wgrad pixel step; also the K granularity the fast paths require (channels % 16 == 0)
 
+struct Geo {
+    int N, H, W, logH, logW;  // logical output grid (per parity class in PC mode)
+    int Hin, Win;             // stored size of the gathered tensor (before the on-the-fly nearest upsample)
+    int ups;                  // gathered coordinates are >> ups
+    int s_in;                 // gather stride (1 or 2)
+    int off_y, off_x;         // iy = oy * s_in + ta + off_y
+    int Th, Tw;               // taps per dimension
+    int KF;                   // taps per dimension of the weight tensor in memory
+    int wa_base, wa_step, wb_base, wb_step;  // weight tap (a, b) = (wa_base + wa_step * ta, wb_base + wb_step * tb)
+    int os, py, px;           // output pixel = (oy * os + py, ox * os + px) in an (H*os) x (W*os) image
+    int pc, pc_kind, pc_K;    // PC mode: blockIdx.z & 3 = class; class parameters derived in the kernel
+};
+
+// class-dependent part of a PC geometry (uniform per workgroup)
+__device__ __forceinline__ void geo_select_class(Geo& g, int cls) {
+    const int py = cls >> 1, px = cls & 1;
+    const int K = g.pc_K, pd = (K - 1) / 2;
+    g.py = py;
+    g.px = px;
+    if (g.pc_kind == 0) {  // conv_KxK(up2(x)), output parity (py, px)
+        const int oy = (py - pd) >> 1, ox = (px - pd) >> 1;  // floor
+        g.off_y = oy;
+        g.off_x = ox;
+        g.wa_base = pd + 1 - py + 2 * oy;
+        g.wb_base = pd + 1 - px + 2 * ox;
+        g.wa_step = g.wb_step = 2;
+    } else {  // dgrad of the stride-2 folded conv, input parity (py, px)
+        const int th = (K + 1) / 2;
+        const int a0 = (py + pd) & 1, b0 = (px + pd) & 1;
+        g.off_y = ((py + pd - a0) >> 1) - (th - 1);
+        g.off_x = ((px + pd - b0) >> 1) - (th - 1);
+        g.wa_base = a0 + 2 * (th - 1);
+        g.wb_base = b0 + 2 * (th - 1);
+        g.wa_step = g.wb_step = -2;
+    }
+}
+
 struct ConvP {
+    Geo g;
     const float* x;
     const float* w;
     const float* bias;
@@ -28,14 +76,13 @@ struct ConvP {
     const float* res;
     const float* mask_x;
     float* y;
-    int N, H, W, logH, logW;
     int Ca, Cb;
-    int KH, pad, ups, T;
     int Cin_w;
     int M;
     int Ktot;
-    float pre_slope, mask_slope;
-    int ksplit;   // > 1: grid.z K-slices, partial results combined with float atomics into a pre-zeroed y
+    float pre_slope, mask_slope, out_scale;
+    int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
+    int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
     int kper;     // K-steps per slice
 };
 
@@ -63,23 +110,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     float* As = lds;
     float* Bs = lds + 2 * A_SZ;
 
+    Geo g = p.g;
+    int kslice = blockIdx.z;
+    if (g.pc) {
+        geo_select_class(g, blockIdx.z & 3);
+        kslice = blockIdx.z >> 2;
+    }
     const int t = threadIdx.x;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int arow = t / QPR, aq = (t % QPR) * 4;
-    const int Hs = p.H >> p.ups, Ws = p.W >> p.ups;
+    const int He = g.Hin << g.ups, We = g.Win << g.ups;  // extent of the (virtually upsampled) gathered image
 
-    int a_oh[A_ROWS], a_ow[A_ROWS];
+    int a_oy[A_ROWS], a_ox[A_ROWS];
     long long a_base[A_ROWS];
     bool a_ok[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
         const int m = m0 + arow + RP * i;
         a_ok[i] = m < p.M;
-        const int n = m >> (p.logH + p.logW);
-        a_oh[i] = (m >> p.logW) & (p.H - 1);
-        a_ow[i] = m & (p.W - 1);
-        a_base[i] = (long long)n * Hs * Ws * p.Ca;
+        const int n = m >> (g.logH + g.logW);
+        a_oy[i] = ((m >> g.logW) & (g.H - 1)) * g.s_in + g.off_y;
+        a_ox[i] = (m & (g.W - 1)) * g.s_in + g.off_x;
+        a_base[i] = (long long)n * g.Hin * g.Win * p.Ca;
     }
 
     f32x4 ra[A_ROWS];
@@ -92,14 +145,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         if constexpr (!GEN) {
             const int tap = k0 / p.Ca;
             const int c0 = k0 - tap * p.Ca;
-            const int kh = tap / p.KH, kw = tap - kh * p.KH;
+            const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
-                const int ih = a_oh[i] + kh - p.pad, iw = a_ow[i] + kw - p.pad;
-                const bool v = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
+                const bool v = a_ok[i] && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (v) {
-                    const float* src = p.x + a_base[i] + (long long)((ih >> p.ups) * Ws + (iw >> p.ups)) * p.Ca + c0 + aq;
+                    const float* src = p.x + a_base[i] + (long long)((iy >> g.ups) * g.Win + (ix >> g.ups)) * p.Ca + c0 + aq;
                     val = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = lrelu_f(val[e], p.pre_slope);
@@ -114,17 +167,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                     const int kf = k0 + aq + e;
                     const int tap = kf / p.Ca;
                     const int c = kf - tap * p.Ca;
-                    const int kh = tap / p.KH, kw = tap - kh * p.KH;
-                    const int ih = a_oh[i] + kh - p.pad, iw = a_ow[i] + kw - p.pad;
-                    const bool v = a_ok[i] && kf < p.Ktot && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
+                    const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
+                    const bool v = a_ok[i] && kf < p.Ktot && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
                     float val = 0.f;
-                    if (v) val = lrelu_f(p.x[a_base[i] + (long long)((ih >> p.ups) * Ws + (iw >> p.ups)) * p.Ca + c], p.pre_slope);
+                    if (v) val = lrelu_f(p.x[a_base[i] + (long long)((iy >> g.ups) * g.Win + (ix >> g.ups)) * p.Ca + c], p.pre_slope);
                     ra[i][e] = val;
                 }
             }
         }
-        // ---- B: weights ----
+        // ---- B: weights; tap (ta, tb) of the loop maps to tap (wa, wb) of the stored tensor ----
         if constexpr (BMODE == 0) {
+            int wtap_u = 0, c0_u = 0;
+            if constexpr (!GEN) {
+                const int tap = k0 / p.Ca;
+                c0_u = k0 - tap * p.Ca;
+                const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
+                wtap_u = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
+            }
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) {
                 const int row = arow + RP * i;
@@ -132,62 +192,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (row < BN && co < p.Cb) {
                     if constexpr (!GEN) {
-                        val = *reinterpret_cast<const f32x4*>(p.w + (long long)co * p.Ktot + k0 + aq);
+                        val = *reinterpret_cast<const f32x4*>(p.w + ((long long)co * g.KF * g.KF + wtap_u) * p.Cin_w + c0_u + aq);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int kf = k0 + aq + e;
-                            if (kf < p.Ktot) val[e] = p.w[(long long)co * p.Ktot + kf];
+                            if (kf < p.Ktot) {
+                                const int tap = kf / p.Ca, c = kf - tap * p.Ca;
+                                const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
+                                const int wt = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
+                                val[e] = p.w[((long long)co * g.KF * g.KF + wt) * p.Cin_w + c];
+                            }
                         }
                     }
                 }
                 rb0[i] = val;
             }
         } else {
-            int tap_u = 0, c0_u = 0;
+            int wtap_u = 0, c0_u = 0;
             if constexpr (!GEN) {
-                tap_u = k0 / p.Ca;
-                c0_u = k0 - tap_u * p.Ca;
+                const int tap = k0 / p.Ca;
+                c0_u = k0 - tap * p.Ca;
+                const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
+                wtap_u = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
             }
+            auto wrow = [&](int krow, bool& v) -> long long {  // offset of weight row (channel ca, mapped tap)
+                int wt = wtap_u, ca = c0_u + krow;
+                if constexpr (GEN) {
+                    const int kf = k0 + krow;
+                    const int tap = kf / p.Ca;
+                    ca = kf - tap * p.Ca;
+                    const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
+                    wt = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
+                    v = v && kf < p.Ktot;
+                }
+                return ((long long)ca * g.KF * g.KF + wt) * p.Cin_w;
+            };
             if constexpr (BSCALAR) {
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
                     const int idx = t + 256 * i;
                     const int krow = idx / BN, col = idx % BN;
-                    int tap, ca;
                     bool v = true;
-                    if constexpr (!GEN) {
-                        tap = tap_u;
-                        ca = c0_u + krow;
-                    } else {
-                        const int kf = k0 + krow;
-                        tap = kf / p.Ca;
-                        ca = kf - tap * p.Ca;
-                        v = kf < p.Ktot;
-                    }
+                    const long long ro = wrow(krow, v);
                     const int ci = n0 + col;
                     v = v && ci < p.Cb;
-                    rb1[i] = v ? p.w[((long long)ca * p.T + (p.T - 1 - tap)) * p.Cin_w + ci] : 0.f;
+                    rb1[i] = v ? p.w[ro + ci] : 0.f;
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < B_PER4; ++i) {
                     const int krow = t / B_U + i * B_RSTEP, col = (t % B_U) * 4;
-                    int tap, ca;
                     bool v = krow < KB;
-                    if constexpr (!GEN) {
-                        tap = tap_u;
-                        ca = c0_u + krow;
-                    } else {
-                        const int kf = k0 + krow;
-                        tap = kf / p.Ca;
-                        ca = kf - tap * p.Ca;
-                        v = v && kf < p.Ktot;
-                    }
+                    const long long ro = wrow(krow, v);
                     const int ci = n0 + col;
                     v = v && ci < p.Cb;  // Cb % 4 == 0 on this path: the whole quad is in range
                     f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (v) val = *reinterpret_cast<const f32x4*>(p.w + ((long long)ca * p.T + (p.T - 1 - tap)) * p.Cin_w + ci);
+                    if (v) val = *reinterpret_cast<const f32x4*>(p.w + ro + ci);
                     rb4[i] = val;
                 }
             }
@@ -230,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk_all = (p.Ktot + KB - 1) / KB;
-    const int ks0 = blockIdx.z * p.kper;
+    const int ks0 = kslice * p.kper;
     const int nk = min(nk_all, ks0 + p.kper);
     load_tiles(ks0 * KB);
     store_tiles(ks0 & 1);
@@ -266,23 +327,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         __syncthreads();
     }
 
-    // ---- epilogue: scale by 1/sigma, bias, residual, activation mask ----
-    const float inv_sigma = p.sigma ? 1.0f / p.sigma[0] : 1.0f;
+    // ---- epilogue: out_scale/sigma, bias, residual, activation mask; logical pixel -> stored pixel ----
+    const float scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
+    const bool first = kslice == 0;
+    const int Ho = g.H * g.os, Wo = g.W * g.os;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int co = n0 + wn0 + 32 * j + r;
             if (co >= p.Cb) continue;
-            const bool first = blockIdx.z == 0;
             const float bv = (p.bias && first) ? p.bias[co] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m >= p.M) continue;
-                const long long o = (long long)m * p.Cb + co;
-                float v = acc[i][j][e] * inv_sigma + bv;
-                if (p.res && first) v += p.res[o];
+                const int n = m >> (g.logH + g.logW);
+                const int oy = ((m >> g.logW) & (g.H - 1)) * g.os + g.py;
+                const int ox = (m & (g.W - 1)) * g.os + g.px;
+                const long long o = (((long long)n * Ho + oy) * Wo + ox) * p.Cb + co;
+                float v = acc[i][j][e] * scale + bv;
+                if (p.res && first) {
+                    const long long ro = p.res_ups ? (((long long)n * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * p.Cb + co : o;
+                    v += p.res[ro];
+                }
                 if (p.mask_x) v *= (p.mask_x[o] > 0.f ? 1.0f : p.mask_slope);
                 if (p.ksplit > 1) atomicAdd(&p.y[o], v);
                 else p.y[o] = v;
@@ -294,17 +362,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 // wgrad
 // -------------------------------------------------------------------------------------------------
 struct WgP {
+    Geo g;             // logical grid = pixels of dy; gather geometry of x (plain or stride 2)
     const float* dy;
     const float* x;
     float* slabs;
     float* bias_slabs;
-    int N, H, W, logH, logW;
-    int Cin, Cout;
-    int KH, pad, ups, T;
+    int Cin, Cout;     // channels of x / of dy (roles as seen by this kernel)
     int M;
     int Kcols;
     int mper;
-    float pre_slope;
+    float pre_slope;   // leaky-relu on the gathered x operand
+    float a_slope;     // leaky-relu on the dy operand (role-swapped use: sub-pixel conv wgrad)
 };
 
 // VEC = 4: dY rows and gathered x rows are fetched as float4 (Cout % 4 == 0, Cin % 4 == 0, 16-byte aligned
@@ -322,11 +390,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
+    const Geo& g = p.g;
     const int t = threadIdx.x;
     const int j0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
     const int mbeg = blockIdx.z * p.mper;
     const int mend = min(p.M, mbeg + p.mper);
-    const int Hs = p.H >> p.ups, Ws = p.W >> p.ups;
+    const int He = g.Hin << g.ups, We = g.Win << g.ups;
 
     const int ac = (t % AU) * VEC, ak = t / AU;
     const bool a_cok = (co0 + ac) < p.Cout;
@@ -335,8 +404,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     const bool b_jok = j < p.Kcols;
     const int tap = b_jok ? j / p.Cin : 0;
     const int ci = b_jok ? j - tap * p.Cin : 0;
-    const int kh = tap / p.KH, kw = tap - kh * p.KH;
-    const int dh = kh - p.pad, dw = kw - p.pad;
+    const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
+    const int dh = ta + g.off_y, dw = tb + g.off_x;
     const bool do_bias = p.bias_slabs != nullptr && blockIdx.x == 0;
 
     float ra[A_PER][VEC], rb[B_PER][VEC];
@@ -354,9 +423,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (v) val = *reinterpret_cast<const f32x4*>(p.dy + (long long)m * p.Cout + co0 + ac);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ra[i][e] = val[e];
+                for (int e = 0; e < 4; ++e) ra[i][e] = lrelu_f(val[e], p.a_slope);
             } else {
-                ra[i][0] = v ? p.dy[(long long)m * p.Cout + co0 + ac] : 0.f;
+                ra[i][0] = v ? lrelu_f(p.dy[(long long)m * p.Cout + co0 + ac], p.a_slope) : 0.f;
             }
             if (do_bias) {
 #pragma unroll
@@ -367,11 +436,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         for (int i = 0; i < B_PER; ++i) {
             const int row = bk + i * B_RSTEP;
             const int m = mb + row;
-            const int n = m >> (p.logH + p.logW);
-            const int ih = ((m >> p.logW) & (p.H - 1)) + dh;
-            const int iw = (m & (p.W - 1)) + dw;
-            const bool v = b_jok && row < BK && m < mend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const long long off = ((long long)(n * Hs + (ih >> p.ups)) * Ws + (iw >> p.ups)) * p.Cin + ci;
+            const int n = m >> (g.logH + g.logW);
+            const int iy = ((m >> g.logW) & (g.H - 1)) * g.s_in + dh;
+            const int ix = (m & (g.W - 1)) * g.s_in + dw;
+            const bool v = b_jok && row < BK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
+            const long long off = ((long long)(n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci;
             if constexpr (VEC == 4) {
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (v) val = *reinterpret_cast<const f32x4*>(p.x + off);
@@ -473,19 +542,92 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// folded weights: F[co][a][b][ci] = sum_{dh,dw in {0,1}} W[co][a-dh][b-dw][ci],  a, b in [0, K]
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_weights_kernel(const float* __restrict__ w, float* __restrict__ f, int Cout, int Cin, int K) {
+    const int KF = K + 1;
+    const long long n = (long long)Cout * KF * KF * Cin;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        long long rr = i / Cin;
+        const int b = (int)(rr % KF); rr /= KF;
+        const int a = (int)(rr % KF);
+        const int co = (int)(rr / KF);
+        float s = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const int kh = a - dh, kw = b - dw;
+                if (kh >= 0 && kh < K && kw >= 0 && kw < K) s += w[(((long long)co * K + kh) * K + kw) * Cin + ci];
+            }
+        f[i] = s;
+    }
+}
+
+extern "C" int gim_conv2d_fold_weights(const float* w, float* f, int Cout, int Cin, int KH, void* stream) {
+    GIM_CHECK_ARG(w && f && Cout > 0 && Cin > 0 && KH > 0 && (KH & 1), "fold_weights: bad args");
+    const long long n = (long long)Cout * (KH + 1) * (KH + 1) * Cin;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fold_weights_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, w, f, Cout, Cin, KH);
+    return gim_check_launch("gim_conv2d_fold_weights");
+}
+
+// -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
-static int fill_common(const gim_conv_shape* s, int* logH, int* logW) {
+static int check_shape(const gim_conv_shape* s) {
     GIM_CHECK_ARG(s != nullptr, "conv: null shape");
     GIM_CHECK_ARG(s->N > 0 && s->Cin > 0 && s->Cout > 0, "conv: non-positive dims");
-    GIM_CHECK_ARG(s->KH == 1 || s->KH == 3 || s->KH == 9 || (s->KH > 0 && (s->KH & 1)), "conv: KH must be odd");
+    GIM_CHECK_ARG(s->KH > 0 && (s->KH & 1), "conv: KH must be odd");
     GIM_CHECK_ARG(s->ups == 0 || s->ups == 1, "conv: ups must be 0 or 1");
-    *logH = ilog2_exact(s->H);
-    *logW = ilog2_exact(s->W);
-    GIM_CHECK_ARG(*logH >= 0 && *logW >= 0, "conv: H and W must be powers of two");
+    GIM_CHECK_ARG(ilog2_exact(s->H) >= 0 && ilog2_exact(s->W) >= 0, "conv: H and W must be powers of two");
     GIM_CHECK_ARG(!s->ups || (s->H >= 2 && s->W >= 2), "conv: ups needs H, W >= 2");
+    GIM_CHECK_ARG(!s->pool || (!s->ups && s->H >= 2 && s->W >= 2 && s->wfold), "conv: pool needs ups == 0, H, W >= 2 and folded weights");
+    GIM_CHECK_ARG(!s->wfold || s->pool || s->ups, "conv: wfold only with pool or ups");
     GIM_CHECK_ARG((long long)s->N * s->H * s->W < (1ll << 31), "conv: too many output pixels");
     return GIM_OK;
+}
+
+static void geo_grid(Geo& g, int N, int H, int W) {
+    g.N = N; g.H = H; g.W = W; g.logH = ilog2_exact(H); g.logW = ilog2_exact(W);
+}
+
+static Geo geo_plain(const gim_conv_shape* s, bool flip) {
+    Geo g{};
+    const int pad = (s->KH - 1) / 2;
+    geo_grid(g, s->N, s->H, s->W);
+    g.ups = flip ? 0 : s->ups;
+    g.Hin = s->H >> g.ups; g.Win = s->W >> g.ups;
+    g.s_in = 1; g.off_y = g.off_x = -pad; g.Th = g.Tw = g.KF = s->KH;
+    g.wa_base = g.wb_base = flip ? s->KH - 1 : 0;
+    g.wa_step = g.wb_step = flip ? -1 : 1;
+    g.os = 1;
+    return g;
+}
+
+// stride-2 gather over the (K+1)^2 folded taps: logical grid (H/2, W/2), gathered image (H, W)
+static Geo geo_s2(const gim_conv_shape* s, bool flip) {
+    Geo g{};
+    const int pad = (s->KH - 1) / 2, KF = s->KH + 1;
+    geo_grid(g, s->N, s->H / 2, s->W / 2);
+    g.Hin = s->H; g.Win = s->W; g.ups = 0;
+    g.s_in = 2; g.off_y = g.off_x = -pad; g.Th = g.Tw = g.KF = KF;
+    g.wa_base = g.wb_base = flip ? KF - 1 : 0;
+    g.wa_step = g.wb_step = flip ? -1 : 1;
+    g.os = 1;
+    return g;
+}
+
+// 4 parity classes: logical grid (H/2, W/2), output image (H, W), gathered image (H/2, W/2)
+static Geo geo_pc(const gim_conv_shape* s, int kind) {
+    Geo g{};
+    geo_grid(g, s->N, s->H / 2, s->W / 2);
+    g.Hin = s->H / 2; g.Win = s->W / 2; g.ups = 0;
+    g.s_in = 1; g.Th = g.Tw = (s->KH + 1) / 2; g.KF = s->KH + 1;
+    g.os = 2; g.pc = 1; g.pc_kind = kind; g.pc_K = s->KH;
+    return g;
 }
 
 // K step 32 measured SLOWER on MI355X (104 vs 111 episodes/s: 73 KB of LDS per workgroup leaves 2 waves per
@@ -493,8 +635,8 @@ static int fill_common(const gim_conv_shape* s, int* logH, int* logW) {
 static const bool g_force_kb16 = getenv("GIM_CONV_KB32") == nullptr;
 
 // Small-M layers (4x4x512 maps, the decoder head, linears on <= 240 rows) have too few output tiles to fill
-// 256 CUs and are bound by the latency of their long K loop: slice K over grid.z until there are ~2 workgroups
-// per CU, each keeping >= 8 K-steps.
+// 256 CUs and are bound by the latency of their long K loop: slice K over grid.z until there is about one
+// workgroup per CU, each keeping >= 8 K-steps.
 static int plan_ksplit(long long wgs, int nk) {
     if (wgs >= 192 || nk < 16) return 1;
     long long ks = (256 + wgs - 1) / wgs;
@@ -504,89 +646,103 @@ static int plan_ksplit(long long wgs, int nk) {
 }
 
 template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int KB>
-static void launch_cfg_kb(ConvP p, hipStream_t st) {
+static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
+    const int ncls = p.g.pc ? 4 : 1;
     const int nk = (p.Ktot + KB - 1) / KB;
-    p.ksplit = plan_ksplit((long long)gx * gy, nk);
+    p.ksplit = plan_ksplit((long long)gx * gy * ncls, nk);
     p.kper = (nk + p.ksplit - 1) / p.ksplit;
     p.ksplit = (nk + p.kper - 1) / p.kper;
-    if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, (size_t)p.M * p.Cb * sizeof(float), st);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB>), dim3(gx, gy, p.ksplit), dim3(256), 0, st, p);
+    if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB>), dim3(gx, gy, p.ksplit * ncls), dim3(256), 0, st, p);
 }
 
-// K step 32 halves the barriers and LDS round trips per FLOP; it needs the gathered channel count to be a
-// multiple of 32 (and the vector paths); the large 128-row tiles are the ones that profit.
 template <int BM, int BN, int TM, int TN, int BMODE, int GEN>
-static void launch_cfg(const ConvP& p, hipStream_t st) {
+static void launch_cfg(const ConvP& p, size_t y_elems, hipStream_t st) {
     if constexpr ((GEN & 1) == 0 && BM == 128) {
         if (p.Ca % 32 == 0 && !g_force_kb16) {
-            launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 32>(p, st);
+            launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 32>(p, y_elems, st);
             return;
         }
     }
-    launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 16>(p, st);
+    launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 16>(p, y_elems, st);
 }
 
 template <int BMODE, int GEN>
-static void launch_igemm(const ConvP& p, hipStream_t st) {
+static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K
     const int M = p.M, Cb = p.Cb;
     if (Cb > 64) {
-        if (M <= 64) launch_cfg<64, 128, 1, 2, BMODE, GEN>(p, st);
-        else launch_cfg<128, 128, 2, 2, BMODE, GEN>(p, st);
+        if (M <= 64) launch_cfg<64, 128, 1, 2, BMODE, GEN>(p, y_elems, st);
+        else launch_cfg<128, 128, 2, 2, BMODE, GEN>(p, y_elems, st);
     } else if (Cb > 32) {
-        if (M <= 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, st);
-        else launch_cfg<128, 64, 2, 1, BMODE, GEN>(p, st);
+        if (M <= 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
+        else launch_cfg<128, 64, 2, 1, BMODE, GEN>(p, y_elems, st);
     } else {
-        launch_cfg<128, 32, 1, 1, BMODE, GEN>(p, st);
+        launch_cfg<128, 32, 1, 1, BMODE, GEN>(p, y_elems, st);
     }
 }
 
 extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias, const float* sigma, const float* residual,
                               float* y, const gim_conv_shape* s, void* stream) {
-    int logH, logW;
-    int rc = fill_common(s, &logH, &logW);
+    int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(x && w && y, "conv fwd: null pointer");
-    ConvP p;
+    ConvP p{};
+    const bool up_fold = s->ups && s->wfold;
+    p.g = s->pool ? geo_s2(s, false) : (up_fold ? geo_pc(s, 0) : geo_plain(s, false));
     p.x = x; p.w = w; p.bias = bias; p.sigma = sigma; p.res = residual; p.mask_x = nullptr; p.y = y;
-    p.N = s->N; p.H = s->H; p.W = s->W; p.logH = logH; p.logW = logW;
-    p.Ca = s->Cin; p.Cb = s->Cout; p.KH = s->KH; p.pad = (s->KH - 1) / 2; p.ups = s->ups; p.T = s->KH * s->KH;
-    p.Cin_w = s->Cin; p.M = s->N * s->H * s->W; p.Ktot = p.T * s->Cin;
-    p.pre_slope = s->pre_slope; p.mask_slope = 1.f;
+    p.Ca = s->Cin; p.Cb = s->Cout; p.Cin_w = s->Cin;
+    p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cin;
+    p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
+    const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
-    if (gen) launch_igemm<0, 1>(p, (hipStream_t)stream);
-    else launch_igemm<0, 0>(p, (hipStream_t)stream);
+    if (gen) launch_igemm<0, 1>(p, y_elems, (hipStream_t)stream);
+    else launch_igemm<0, 0>(p, y_elems, (hipStream_t)stream);
     return gim_check_launch("gim_conv2d_fwd");
 }
 
 extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
                                 const gim_conv_shape* s, void* stream) {
-    int logH, logW;
-    int rc = fill_common(s, &logH, &logW);
+    int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(dy && w && dx, "conv dgrad: null pointer");
-    GIM_CHECK_ARG(!(mask_x && s->ups), "conv dgrad: mask_x is only legal for ups == 0");
-    ConvP p;
+    const bool up_fold = s->ups && s->wfold;
+    GIM_CHECK_ARG(!(mask_x && s->ups && !up_fold), "conv dgrad: mask_x with ups == 1 needs folded weights");
+    ConvP p{};
+    // pool: dx [N,H,W,Cin] from dy [N,H/2,W/2,Cout] by input-parity classes; sub-pixel (ups+wfold): dx
+    // [N,H/2,W/2,Cin] directly from dy [N,H,W,Cout] by a stride-2 gather; plain: dx at the conv's resolution
+    p.g = s->pool ? geo_pc(s, 1) : (up_fold ? geo_s2(s, true) : geo_plain(s, true));
     p.x = dy; p.w = w; p.bias = nullptr; p.sigma = sigma; p.res = nullptr; p.mask_x = mask_x; p.y = dx;
-    p.N = s->N; p.H = s->H; p.W = s->W; p.logH = logH; p.logW = logW;
-    p.Ca = s->Cout; p.Cb = s->Cin; p.KH = s->KH; p.pad = (s->KH - 1) / 2; p.ups = 0; p.T = s->KH * s->KH;
-    p.Cin_w = s->Cin; p.M = s->N * s->H * s->W; p.Ktot = p.T * s->Cout;
-    p.pre_slope = 1.f; p.mask_slope = s->pre_slope;
+    p.Ca = s->Cout; p.Cb = s->Cin; p.Cin_w = s->Cin;
+    p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cout;
+    p.pre_slope = 1.f; p.mask_slope = s->pre_slope; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = 0;
+    const size_t y_elems = (size_t)s->N * (s->H >> (up_fold ? 1 : 0)) * (s->W >> (up_fold ? 1 : 0)) * s->Cin;
     const bool gen = (s->Cout % BK) != 0 || ((uintptr_t)dy & 15);
     const bool bscalar = (s->Cin % 4) != 0 || ((uintptr_t)w & 15);
     hipStream_t st = (hipStream_t)stream;
-    if (gen) { if (bscalar) launch_igemm<1, 3>(p, st); else launch_igemm<1, 1>(p, st); }
-    else     { if (bscalar) launch_igemm<1, 2>(p, st); else launch_igemm<1, 0>(p, st); }
+    if (gen) { if (bscalar) launch_igemm<1, 3>(p, y_elems, st); else launch_igemm<1, 1>(p, y_elems, st); }
+    else     { if (bscalar) launch_igemm<1, 2>(p, y_elems, st); else launch_igemm<1, 0>(p, y_elems, st); }
     return gim_check_launch("gim_conv2d_dgrad");
 }
 
-static void wgrad_plan(const gim_conv_shape* s, int* bm, int* bn, int* nslab, int* mper) {
-    const int Kcols = s->KH * s->KH * s->Cin;
-    const long long M = (long long)s->N * s->H * s->W;
-    *bm = s->Cout > 64 ? 128 : (s->Cout > 32 ? 64 : 32);
-    *bn = (*bm == 32) ? 128 : (Kcols > 64 ? 128 : 64);
-    const long long tiles = (long long)((Kcols + *bn - 1) / *bn) * ((s->Cout + *bm - 1) / *bm);
+// wgrad roles.  plain: A = dy [N,H,W,Cout], B = gathered x.  pool: A = dy [N,H/2,W/2,Cout], B = x gathered with
+// stride 2 over the (K+1)^2 folded taps -> slabs in F layout [Cout][KF][KF][Cin].  sub-pixel (ups + wfold), roles
+// swapped: A = leaky_relu(x) [N,H/2,W/2,Cin], B = dy [N,H,W,Cout] gathered with stride 2 -> slabs
+// G[Cin][KF][KF][Cout] with G[ci][ta][tb][co] = dF[co][K-ta][K-tb][ci] (gim_wgrad_finish un-transposes).
+struct WgPlan { int bm, bn, ns, mper, rows, cols, M; };
+
+static WgPlan wgrad_plan(const gim_conv_shape* s) {
+    WgPlan q;
+    const bool up_fold = s->ups && s->wfold;
+    const int KF = s->wfold ? s->KH + 1 : s->KH;
+    q.rows = up_fold ? s->Cin : s->Cout;
+    q.cols = KF * KF * (up_fold ? s->Cout : s->Cin);
+    const long long M = (long long)s->N * (s->H >> (s->wfold ? 1 : 0)) * (s->W >> (s->wfold ? 1 : 0));
+    q.M = (int)M;
+    q.bm = q.rows > 64 ? 128 : (q.rows > 32 ? 64 : 32);
+    q.bn = (q.bm == 32) ? 128 : (q.cols > 64 ? 128 : 64);
+    const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
     // about two workgroups per CU in total, and at least 32 K-steps (512 pixels) per workgroup so that the
     // slab write + later slab reduction stay small next to the MFMA work
     long long S = (512 + tiles - 1) / tiles;
@@ -596,16 +752,14 @@ static void wgrad_plan(const gim_conv_shape* s, int* bm, int* bn, int* nslab, in
     if (S < 1) S = 1;
     long long mp = (M + S - 1) / S;
     mp = (mp + BK - 1) / BK * BK;
-    *mper = (int)mp;
-    *nslab = (int)((M + mp - 1) / mp);
+    q.mper = (int)mp;
+    q.ns = (int)((M + mp - 1) / mp);
+    return q;
 }
 
 extern "C" int gim_conv2d_wgrad_slabs(const gim_conv_shape* s) {
-    int logH, logW;
-    if (fill_common(s, &logH, &logW)) return GIM_E_BADARG;
-    int bm, bn, ns, mper;
-    wgrad_plan(s, &bm, &bn, &ns, &mper);
-    return ns;
+    if (check_shape(s)) return GIM_E_BADARG;
+    return wgrad_plan(s).ns;
 }
 
 template <int VEC>
@@ -619,21 +773,27 @@ static void launch_wgrad(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
 
 extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs,
                                 const gim_conv_shape* s, void* stream) {
-    int logH, logW;
-    int rc = fill_common(s, &logH, &logW);
+    int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(dy && x && slabs, "conv wgrad: null pointer");
-    int bm, bn, ns, mper;
-    wgrad_plan(s, &bm, &bn, &ns, &mper);
-    GIM_CHECK_ARG(n_slabs == ns, "conv wgrad: n_slabs must equal gim_conv2d_wgrad_slabs(shape)");
-    WgP p;
-    p.dy = dy; p.x = x; p.slabs = slabs; p.bias_slabs = bias_slabs;
-    p.N = s->N; p.H = s->H; p.W = s->W; p.logH = logH; p.logW = logW;
-    p.Cin = s->Cin; p.Cout = s->Cout; p.KH = s->KH; p.pad = (s->KH - 1) / 2; p.ups = s->ups; p.T = s->KH * s->KH;
-    p.M = s->N * s->H * s->W; p.Kcols = p.T * s->Cin; p.mper = mper; p.pre_slope = s->pre_slope;
-    dim3 g((p.Kcols + bn - 1) / bn, (s->Cout + bm - 1) / bm, ns);
+    const WgPlan q = wgrad_plan(s);
+    GIM_CHECK_ARG(n_slabs == q.ns, "conv wgrad: n_slabs must equal gim_conv2d_wgrad_slabs(shape)");
+    const bool up_fold = s->ups && s->wfold;
+    GIM_CHECK_ARG(!(up_fold && bias_slabs), "conv wgrad: the sub-pixel form does not produce the bias gradient (use gim_colsum)");
+    WgP p{};
+    if (s->pool) p.g = geo_s2(s, false);
+    else if (up_fold) p.g = geo_s2(s, false);
+    else p.g = geo_plain(s, false);
+    if (up_fold) {
+        p.dy = x; p.x = dy; p.Cin = s->Cout; p.Cout = s->Cin; p.pre_slope = 1.f; p.a_slope = s->pre_slope;
+    } else {
+        p.dy = dy; p.x = x; p.Cin = s->Cin; p.Cout = s->Cout; p.pre_slope = s->pre_slope; p.a_slope = 1.f;
+    }
+    p.slabs = slabs; p.bias_slabs = bias_slabs;
+    p.M = q.M; p.Kcols = q.cols; p.mper = q.mper;
+    dim3 g((q.cols + q.bn - 1) / q.bn, (q.rows + q.bm - 1) / q.bm, q.ns);
     const bool vec = (s->Cin % 4 == 0) && (s->Cout % 4 == 0) && !(((uintptr_t)dy | (uintptr_t)x) & 15);
-    if (vec) launch_wgrad<4>(p, bm, bn, g, (hipStream_t)stream);
-    else launch_wgrad<1>(p, bm, bn, g, (hipStream_t)stream);
+    if (vec) launch_wgrad<4>(p, q.bm, q.bn, g, (hipStream_t)stream);
+    else launch_wgrad<1>(p, q.bm, q.bn, g, (hipStream_t)stream);
     return gim_check_launch("gim_conv2d_wgrad");
 }

@@ -144,6 +144,40 @@ __global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* __restrict_
     }
 }
 
+// fold 1: src = dF [Cout][KF][KF][Cin]:  dW[co][kh][kw][ci] = 0.25 * sum_{dh,dw} dF[co][kh+dh][kw+dw][ci]
+// fold 2: src = G  [Cin][KF][KF][Cout] with dF[co][a][b][ci] = G[ci][K-a][K-b][co]:  dW = sum_{dh,dw} dF[..][kh+dh][kw+dw][..]
+__global__ __launch_bounds__(256) void wgrad_unfold_kernel(const float* __restrict__ src, const float* __restrict__ w,
+                                                           float* __restrict__ dw, float* __restrict__ partial, int Cout, int Cin,
+                                                           int K, int fold) {
+    __shared__ float red[4];
+    const int KF = K + 1;
+    const long long n = (long long)Cout * K * K * Cin;
+    float dot = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        long long rr = i / Cin;
+        const int kw = (int)(rr % K); rr /= K;
+        const int kh = (int)(rr % K);
+        const int co = (int)(rr / K);
+        float g = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dwd = 0; dwd < 2; ++dwd) {
+                const int a = kh + dh, b = kw + dwd;
+                if (fold == 1) g += src[(((long long)co * KF + a) * KF + b) * Cin + ci];
+                else g += src[(((long long)ci * KF + (K - a)) * KF + (K - b)) * Cout + co];
+            }
+        if (fold == 1) g *= 0.25f;
+        dw[i] = g;
+        if (w) dot += g * w[i];
+    }
+    if (partial) {
+        dot = block_sum_256(dot, red);
+        if (threadIdx.x == 0) partial[blockIdx.x] = dot;
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_sn_apply_kernel(float* __restrict__ dw, const float* __restrict__ partial, int n_part,
                                                              const float* __restrict__ sigma, const float* __restrict__ u,
                                                              const float* __restrict__ v, long long n, int Cin, int T) {
@@ -165,18 +199,31 @@ __global__ __launch_bounds__(256) void wgrad_sn_apply_kernel(float* __restrict__
 
 extern "C" int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int n_slabs, const float* w, const float* sigma,
                                 const float* u, const float* v, float* dw, float* db, float* scratch, int Cout, int Cin, int KH,
-                                void* stream) {
+                                int fold, void* stream) {
     GIM_CHECK_ARG(slabs && dw && n_slabs > 0, "wgrad_finish: bad args");
     GIM_CHECK_ARG(!db || bias_slabs, "wgrad_finish: db needs bias_slabs");
     GIM_CHECK_ARG(!sigma || (w && u && v && scratch), "wgrad_finish: spectral form needs w, u, v, scratch");
+    GIM_CHECK_ARG(fold >= 0 && fold <= 2 && (!fold || scratch), "wgrad_finish: bad fold / missing scratch");
     hipStream_t st = (hipStream_t)stream;
     const int T = KH * KH;
     const long long n = (long long)Cout * Cin * T;
     int blocks = (int)((n + 1023) / 1024);
     if (blocks > WF_BLOCKS) blocks = WF_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(wgrad_sum_kernel, dim3(blocks), dim3(256), 0, st, slabs, n_slabs, n, sigma ? w : nullptr, dw,
-                       sigma ? scratch : nullptr, bias_slabs, db, Cout);
+    if (fold == 0) {
+        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(blocks), dim3(256), 0, st, slabs, n_slabs, n, sigma ? w : nullptr, dw,
+                           sigma ? scratch : nullptr, bias_slabs, db, Cout);
+    } else {
+        // 1) sum the slabs (folded layout) into scratch[512 ...], bias on the way; 2) un-fold into dw (+ <g, w>)
+        const long long nf = (long long)Cout * Cin * (KH + 1) * (KH + 1);
+        float* fsum = scratch + WF_BLOCKS;
+        int fb = (int)((nf + 1023) / 1024);
+        if (fb > WF_BLOCKS) fb = WF_BLOCKS;
+        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(fb), dim3(256), 0, st, slabs, n_slabs, nf, (const float*)nullptr, fsum,
+                           (float*)nullptr, bias_slabs, db, Cout);
+        hipLaunchKernelGGL(wgrad_unfold_kernel, dim3(blocks), dim3(256), 0, st, fsum, sigma ? w : nullptr, dw,
+                           sigma ? scratch : nullptr, Cout, Cin, KH, fold);
+    }
     if (sigma)
         hipLaunchKernelGGL(wgrad_sn_apply_kernel, dim3(blocks), dim3(256), 0, st, dw, scratch, blocks, sigma, u, v, n, Cin, T);
     return gim_check_launch("gim_wgrad_finish");

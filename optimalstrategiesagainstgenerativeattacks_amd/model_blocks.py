@@ -7,9 +7,11 @@ their order and ``parameters()`` order are those of the reference, incl. the spe
 kernels (``ops.py`` -> ``libgim_hip.so``) on NHWC activations, with the element-wise neighbours of each
 convolution fused into it:
 
-  LeakyReLU / nearest-upsample in front of a conv  -> conv prologue (gather)
+  LeakyReLU in front of a conv                     -> conv prologue (gather)
   1/sigma of spectral norm, bias, residual add     -> conv epilogue
-  avgpool(left) + avgpool(right)                   -> one avgpool of the summed branches (linearity)
+  AvgPool2d(2) behind a conv                       -> folded into ONE stride-2 conv (16/36 of the FLOPs for 3x3)
+  nearest-upsample in front of a KxK conv          -> sub-pixel form on the low-resolution input (same ratio)
+  1x1 skip convs next to a pool / upsample         -> computed at the low resolution
 
 Unless noted, tensors between blocks are NHWC ``[N, H, W, C]`` float32 on the GPU.
 """
@@ -109,12 +111,12 @@ class SNConv2d(nn.Module):
 
         self._sn_queue = collections.deque()  # (sigma, u, v) triples precomputed by an SNPlan round
 
-    def forward(self, x, res=None, ups=0, pre_slope=1.0):
+    def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False):
         if self._sn_queue:
             sigma, u_s, v_s = self._sn_queue.popleft()
         else:
             sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
-        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope)
+        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d (spectral norm)" % (self.in_channels, self.out_channels, self.kernel_size)
@@ -214,7 +216,9 @@ def custom_std(x):
 
 
 class ResBlockDown(nn.Module):
-    """models/model_blocks.py:486-514.  avgpool(l) + avgpool(r) is computed as avgpool(l + r)."""
+    """models/model_blocks.py:486-514, with both average pools folded away (exact in real arithmetic):
+    avgpool(conv1x1(x)) = conv1x1(avgpool(x)) for the skip, and avgpool(conv_r2(.)) + skip is ONE stride-2
+    convolution with the 2x2-folded weights and the low-resolution skip as its epilogue residual."""
 
     def __init__(self, in_channel, out_channel, conv_size=3, padding_size=1):
         super().__init__()
@@ -223,10 +227,9 @@ class ResBlockDown(nn.Module):
         self.conv_r2 = SNConv2d(out_channel, out_channel, conv_size, padding=padding_size)
 
     def forward(self, x):
-        left = self.conv_l1(x)
+        left = self.conv_l1(ops.avg_pool2(x))
         out = self.conv_r1(x, pre_slope=LRELU)
-        out = self.conv_r2(out, res=left, pre_slope=LRELU)
-        return ops.avg_pool2(out)
+        return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True)
 
 
 class SelfAttention(nn.Module):
@@ -294,11 +297,13 @@ class ResBlockUp(nn.Module):
         self.conv_r2 = SNConv2d(out_channel, out_channel, conv_size, padding=padding_size)
 
     def forward(self, x):
-        left = self.conv_l1(x, ups=1)
+        # conv1x1(up(x)) = up(conv1x1(x)): the skip is computed at low resolution and upsampled by the residual
+        # read of conv_r2; conv_r1(up(.)) runs in its sub-pixel form (ops.ConvFn)
+        left = self.conv_l1(x)
         out = self.in1(x)
         out = self.conv_r1(out, ups=1, pre_slope=LRELU)
         out = self.in2(out)
-        return self.conv_r2(out, res=left, pre_slope=LRELU)
+        return self.conv_r2(out, res=left, res_ups=True, pre_slope=LRELU)
 
 
 class AdaResBlock2(nn.Module):
@@ -341,8 +346,8 @@ class AdaResBlockUp2(nn.Module):
     def forward(self, x, style):
         m1, s1 = self.lin1_mean(style), self.lin1_std(style)
         m2, s2 = self.lin2_mean(style), self.lin2_std(style)
-        left = self.conv_l1(x, ups=1)
+        left = self.conv_l1(x)
         out = ops.ada_in(x, m1, s1)
         out = self.conv_r1(out, ups=1, pre_slope=LRELU)
         out = ops.ada_in(out, m2, s2)
-        return self.conv_r2(out, res=left, pre_slope=LRELU)
+        return self.conv_r2(out, res=left, res_ups=True, pre_slope=LRELU)

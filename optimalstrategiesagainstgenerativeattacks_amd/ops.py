@@ -39,8 +39,8 @@ def weight_phys(w):
     return wp if wp.is_contiguous() else wp.contiguous()
 
 
-def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope):
-    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope)
+def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
+    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups)
 
 
 # --------------------------------------------------------------------------------------------
@@ -63,14 +63,25 @@ def spectral_sigma(w, u, v, training):
     return sigma, u_s, v_s
 
 
+def _folded(wp, Cout, Cin, KH):
+    """(KH+1)^2-tap folded weights F (sum of the 2x2-shifted copies of W) for the pool / sub-pixel forms."""
+    f = torch.empty(Cout * (KH + 1) * (KH + 1) * Cin, device=wp.device, dtype=torch.float32)
+    check(_lib.load().gim_conv2d_fold_weights(_p(wp), _p(f), Cout, Cin, KH, _stream()), "fold_weights")
+    return f
+
+
 # --------------------------------------------------------------------------------------------
 # convolution / linear
 # --------------------------------------------------------------------------------------------
 class ConvFn(Function):
-    """y = conv(up2^ups(lrelu(x, pre_slope)), w) / sigma + bias + res   (NHWC; linear when x is 2-D)."""
+    """y = [avgpool2]( conv(up2^ups(lrelu(x, pre_slope)), w) ) / sigma + bias + res   (NHWC; linear when x is 2-D).
+
+    pool: the 2x2 average pool behind the conv is folded into ONE stride-2 convolution; ups with a KxK kernel
+    (K > 1) runs in its sub-pixel form on the low-resolution input: neither pooling nor upsampling costs conv FLOPs.
+    res_ups: the residual is stored at half the output resolution."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope):
+    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups):
         lib = _lib.load()
         x = _req(x, "x")
         wp = weight_phys(_req_w(w))
@@ -83,62 +94,77 @@ class ConvFn(Function):
         if w.shape[1] != Cin:
             raise RuntimeError("conv: weight expects %d input channels, got %d" % (w.shape[1], Cin))
         H, W = Hs << ups, Ws << ups
-        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope)
-        y = torch.empty((N, Cout) if x.dim() == 2 else (N, H, W, Cout), device=x.device, dtype=torch.float32)
+        fold = 1 if (pool or (ups and KH > 1)) else 0
+        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
+        Ho, Wo = (H >> 1, W >> 1) if pool else (H, W)
+        y = torch.empty((N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         if res is not None:
             res = _req(res, "res")
-        check(lib.gim_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd")
+        wk = _folded(wp, Cout, Cin, KH) if fold else wp
+        check(lib.gim_conv2d_fwd(_p(x), _p(wk), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd")
         ctx.save_for_backward(x, w, sigma, u_s, v_s)
-        ctx.cfg = (N, H, W, Cin, Cout, KH, ups, pre_slope, bias is not None, res is not None)
+        ctx.cfg = (N, H, W, Cin, Cout, KH, ups, pre_slope, bias is not None, res is not None, bool(pool), fold, bool(res_ups))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         x, w, sigma, u_s, v_s = ctx.saved_tensors
-        N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res = ctx.cfg
+        N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = ctx.cfg
         dy = _req(dy, "dy")
         wp = weight_phys(w)
-        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope)
+        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
         st = _stream()
         dev = dy.device
         dx = dw = db = dres = None
         mask = x if pre_slope != 1.0 else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if ups:
+            wk = _folded(wp, Cout, Cin, KH) if fold else wp
+            if ups and not fold:
                 dxu = torch.empty((N, H, W, Cin), device=dev, dtype=torch.float32)
-                check(lib.gim_conv2d_dgrad(_p(dy), _p(wp), _p(sigma), None, _p(dxu), sh, st), "conv2d_dgrad")
+                check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), None, _p(dxu), sh, st), "conv2d_dgrad")
                 check(lib.gim_upsample2x_bwd(_p(dxu), _p(mask), pre_slope, _p(dx), N, H >> 1, W >> 1, Cin, st), "upsample2x_bwd")
             else:
-                check(lib.gim_conv2d_dgrad(_p(dy), _p(wp), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad")
+                check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad")
         want_w = ctx.needs_input_grad[1]
         want_b = has_bias and ctx.needs_input_grad[2]
+        Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
         if want_w:
             ns = lib.gim_conv2d_wgrad_slabs(sh)
             if ns <= 0:
                 check(ns, "conv2d_wgrad_slabs")
             K = KH * KH * Cin
+            KFF = (KH + 1) * (KH + 1) * Cin if fold else K
             dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
+            slab_bias = want_b and not (fold and ups)  # the role-swapped sub-pixel wgrad does not stream dy as its A operand
             if want_b:
                 db = torch.empty(Cout, device=dev, dtype=torch.float32)
-            if ns == 1 and sigma is None:
-                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(dwp), _p(db), 1, sh, st), "conv2d_wgrad")
+            if ns == 1 and sigma is None and not fold:
+                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(dwp), _p(db) if slab_bias else None, 1, sh, st), "conv2d_wgrad")
             else:
-                slabs = torch.empty(ns * Cout * K, device=dev, dtype=torch.float32)
-                bslabs = torch.empty(ns * Cout, device=dev, dtype=torch.float32) if want_b else None
-                scratch = torch.empty(512, device=dev, dtype=torch.float32)
+                slabs = torch.empty(ns * Cout * KFF, device=dev, dtype=torch.float32)
+                bslabs = torch.empty(ns * Cout, device=dev, dtype=torch.float32) if slab_bias else None
+                scratch = torch.empty(512 + (Cout * KFF if fold else 0), device=dev, dtype=torch.float32)
                 check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(slabs), _p(bslabs), ns, sh, st), "conv2d_wgrad")
-                check(lib.gim_wgrad_finish(_p(slabs), _p(bslabs), ns, _p(wp), _p(sigma), _p(u_s), _p(v_s), _p(dwp), _p(db),
-                                           _p(scratch), Cout, Cin, KH, st), "wgrad_finish")
+                check(lib.gim_wgrad_finish(_p(slabs), _p(bslabs), ns, _p(wp), _p(sigma), _p(u_s), _p(v_s), _p(dwp),
+                                           _p(db) if slab_bias else None, _p(scratch), Cout, Cin, KH,
+                                           (2 if ups else 1) if fold else 0, st), "wgrad_finish")
+            if want_b and not slab_bias:
+                scr = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
+                check(lib.gim_colsum(_p(dy), _p(db), _p(scr), Mo, Cout, st), "colsum")
             dw = dwp.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2) if w.dim() == 4 else dwp.view(Cout, Cin)
         elif want_b:
             db = torch.empty(Cout, device=dev, dtype=torch.float32)
             scratch = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
-            check(lib.gim_colsum(_p(dy), _p(db), _p(scratch), N * H * W, Cout, st), "colsum")
+            check(lib.gim_colsum(_p(dy), _p(db), _p(scratch), Mo, Cout, st), "colsum")
         if has_res and ctx.needs_input_grad[3]:
-            dres = dy
-        return dx, dw, db, dres, None, None, None, None, None
+            if res_ups:
+                dres = torch.empty((N, H >> 1, W >> 1, Cout), device=dev, dtype=torch.float32)
+                check(lib.gim_upsample2x_bwd(_p(dy), None, 1.0, _p(dres), N, H >> 1, W >> 1, Cout, st), "upsample2x_bwd")
+            else:
+                dres = dy
+        return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
 def _req_w(w):
@@ -147,14 +173,14 @@ def _req_w(w):
     return w
 
 
-def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0):
-    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope)
+def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0, pool=False, res_ups=False):
+    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups)
 
 
 def linear(x, w, bias=None, pre_slope=1.0):
     """nn.Linear on the last dim (optionally with a fused LeakyReLU on the input)."""
     shp = x.shape
-    y = ConvFn.apply(x.reshape(-1, shp[-1]), w, bias, None, None, None, None, 0, pre_slope)
+    y = ConvFn.apply(x.reshape(-1, shp[-1]), w, bias, None, None, None, None, 0, pre_slope, False, False)
     return y.view(*shp[:-1], w.shape[0])
 
 

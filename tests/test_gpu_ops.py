@@ -45,6 +45,19 @@ CONV_CASES = [
     (5, 48, 48, 3, 2, 1, 0.2, True, True),         # tiny maps (1x1 -> 2x2)
     (70, 128, 128, 3, 1, 0, 1.0, False, False),    # 1x1 spatial with 3x3 kernel (only centre tap valid)
     (2, 128, 256, 3, 32, 0, 0.2, False, True),     # M=2048: 128-wide tiles
+    (3, 32, 64, 3, 16, 1, 0.2, False, True),       # sub-pixel form, vector paths
+    (2, 16, 16, 9, 8, 1, 1.0, True, False),        # sub-pixel 9x9 (5x5 taps per class)
+]
+
+POOL_CASES = [
+    # N, Cin, Cout, K, H, slope, res
+    (2, 16, 32, 3, 8, 0.2, True),
+    (3, 64, 64, 3, 16, 0.2, True),
+    (2, 3, 8, 3, 16, 0.2, False),       # generic-K
+    (2, 16, 48, 9, 16, 0.2, True),      # 9x9 + pool = 10x10 stride 2
+    (2, 6, 64, 9, 16, 1.0, False),
+    (5, 128, 128, 3, 2, 0.2, True),     # 2x2 -> 1x1
+    (9, 64, 160, 3, 32, 0.2, True),
 ]
 
 
@@ -87,6 +100,58 @@ def test_conv2d_fwd_bwd(case):
     assert relerr(bg.grad.double().cpu(), b.grad) < TOL, "db"
     if use_res:
         assert relerr(nchw(rg.grad), res.grad) < TOL, "dres"
+
+
+@pytest.mark.parametrize("case", POOL_CASES, ids=[str(c) for c in POOL_CASES])
+def test_conv2d_pool_fold(case):
+    """avgpool2(conv(lrelu(x))) + res as ONE stride-2 convolution with folded weights: fwd, dx, dw, db, dres."""
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
+    N, Cin, Cout, K, H, slope, use_res = case
+    tag = "pool%s" % (case,)
+    x = T(pf.normal(tag + "x", (N, Cin, H, H))).requires_grad_()
+    w = T(pf.normal(tag + "w", (Cout, Cin, K, K)) / np.sqrt(Cin * K * K)).requires_grad_()
+    b = T(pf.normal(tag + "b", (Cout,))).requires_grad_()
+    res = T(pf.normal(tag + "r", (N, Cout, H // 2, H // 2))).requires_grad_() if use_res else None
+    sig = 1.3
+    xa = F.leaky_relu(x, slope) if slope != 1.0 else x
+    y = F.avg_pool2d(F.conv2d(xa, w / sig, None, padding=(K - 1) // 2), 2) + b.view(1, -1, 1, 1)
+    if use_res:
+        y = y + res
+    r = T(pf.uniform(tag + "dy", tuple(y.shape)))
+    (y * r).sum().backward()
+    xg = nhwc(x).requires_grad_()
+    wg = cl_weight(w)
+    bg = b.detach().float().to(dev()).requires_grad_()
+    rg = nhwc(res).requires_grad_() if use_res else None
+    sg = torch.tensor([sig], device=dev())
+    u0 = torch.zeros(Cout, device=dev())
+    v0 = torch.zeros(Cin * K * K, device=dev())
+    yg = ops.conv2d(xg, wg, bg, rg, sg, u0, v0, 0, slope, pool=True)
+    assert relerr(nchw(yg), y) < TOL
+    (yg * nhwc(r)).sum().backward()
+    assert relerr(nchw(xg.grad), x.grad) < TOL, "dx"
+    assert relerr(wg.grad.double().cpu(), w.grad) < TOL, "dw"
+    assert relerr(bg.grad.double().cpu(), b.grad) < TOL, "db"
+    if use_res:
+        assert relerr(nchw(rg.grad), res.grad) < TOL, "dres"
+
+
+def test_conv2d_residual_upsampled():
+    """y = conv(x) + up2(res_low): residual stored at half resolution (skip of the up blocks)."""
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
+    N, Cin, Cout, K, H = 2, 16, 24, 3, 8
+    x = T(pf.normal("ru/x", (N, Cin, H, H))).requires_grad_()
+    w = T(pf.normal("ru/w", (Cout, Cin, K, K)) / 12).requires_grad_()
+    res = T(pf.normal("ru/r", (N, Cout, H // 2, H // 2))).requires_grad_()
+    y = F.conv2d(x, w, None, padding=1) + go.upsample2(res)
+    r = T(pf.uniform("ru/dy", tuple(y.shape)))
+    (y * r).sum().backward()
+    xg, wg, rg = nhwc(x).requires_grad_(), cl_weight(w), nhwc(res).requires_grad_()
+    yg = ops.conv2d(xg, wg, None, rg, None, None, None, 0, 1.0, res_ups=True)
+    assert relerr(nchw(yg), y) < TOL
+    (yg * nhwc(r)).sum().backward()
+    assert relerr(nchw(xg.grad), x.grad) < TOL and relerr(wg.grad.double().cpu(), w.grad) < TOL
+    assert relerr(nchw(rg.grad), res.grad) < TOL
 
 
 def test_linear_fwd_bwd():
