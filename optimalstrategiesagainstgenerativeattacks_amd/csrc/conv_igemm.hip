@@ -88,8 +88,11 @@ struct ConvP {
 
 // GENF bit 0: generic K (channel count of the gathered tensor not a multiple of 16, or unaligned base)
 // GENF bit 1: (BMODE 1 only) scalar loads of the k-major weight tile (output channels not a multiple of 4)
+// __launch_bounds__(256, 4): cap the allocation at 128 registers (accumulators included) so that 4 workgroups
+// (40 KB of LDS each at K step 16) share a CU: 4 waves per SIMD hide the global->LDS->MFMA latency of the
+// one-barrier-per-K-step pipeline better than 3 (no spills: 120-126 VGPRs).
 template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
     constexpr bool BSCALAR = (GENF & 2) != 0;
     constexpr int WAVES_N = BN / (32 * TN);

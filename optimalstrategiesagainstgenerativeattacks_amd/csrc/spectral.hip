@@ -119,11 +119,15 @@ extern "C" int gim_spectral_sigma(const float* w, float* u, float* v, float* sig
 // -------------------------------------------------------------------------------------------------
 #define WF_BLOCKS 512
 
+// dw[i] = sum_s slabs[s][i] (+ <dw, w> partials, + bias sums).  64 elements x 4 slab groups per block pass: the
+// slab loop of one element is spread over 4 threads and unrolled, so a 100-slab reduction keeps ~32 independent
+// loads in flight per element instead of one dependent chain.
 __global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* __restrict__ slabs, int n_slabs, long long n,
                                                         const float* __restrict__ w, float* __restrict__ dw,
                                                         float* __restrict__ partial, const float* __restrict__ bias_slabs,
                                                         float* __restrict__ db, int Cout) {
     __shared__ float red[4];
+    __shared__ float part[4][64];
     float dot = 0.f;
     if (db) {
         for (int c = blockIdx.x * 256 + threadIdx.x; c < Cout; c += gridDim.x * 256) {
@@ -132,11 +136,28 @@ __global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* __restrict_
             db[c] = g;
         }
     }
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    for (long long i0 = (long long)blockIdx.x * 64; i0 < n; i0 += (long long)gridDim.x * 64) {
+        const long long i = i0 + el;
         float g = 0.f;
-        for (int s = 0; s < n_slabs; ++s) g += slabs[(long long)s * n + i];
-        dw[i] = g;
-        if (w) dot += g * w[i];
+        if (i < n) {
+            int s = sg;
+#pragma unroll 1
+            for (; s + 12 < n_slabs; s += 16) {
+                const float g0 = slabs[(long long)s * n + i], g1 = slabs[(long long)(s + 4) * n + i];
+                const float g2 = slabs[(long long)(s + 8) * n + i], g3 = slabs[(long long)(s + 12) * n + i];
+                g += (g0 + g1) + (g2 + g3);
+            }
+            for (; s < n_slabs; s += 4) g += slabs[(long long)s * n + i];
+        }
+        part[sg][el] = g;
+        __syncthreads();
+        if (sg == 0 && i < n) {
+            g = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+            dw[i] = g;
+            if (w) dot += g * w[i];
+        }
+        __syncthreads();
     }
     if (partial) {
         dot = block_sum_256(dot, red);
@@ -210,14 +231,17 @@ extern "C" int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int
     int blocks = (int)((n + 1023) / 1024);
     if (blocks > WF_BLOCKS) blocks = WF_BLOCKS;
     if (blocks < 1) blocks = 1;
+    int sblocks = (int)((n + 63) / 64);  // wgrad_sum_kernel: 64 elements per block pass
+    if (sblocks > WF_BLOCKS) sblocks = WF_BLOCKS;
     if (fold == 0) {
-        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(blocks), dim3(256), 0, st, slabs, n_slabs, n, sigma ? w : nullptr, dw,
+        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(sblocks), dim3(256), 0, st, slabs, n_slabs, n, sigma ? w : nullptr, dw,
                            sigma ? scratch : nullptr, bias_slabs, db, Cout);
+        blocks = sblocks;  // number of <g, w> partials for the spectral apply
     } else {
         // 1) sum the slabs (folded layout) into scratch[512 ...], bias on the way; 2) un-fold into dw (+ <g, w>)
         const long long nf = (long long)Cout * Cin * (KH + 1) * (KH + 1);
         float* fsum = scratch + WF_BLOCKS;
-        int fb = (int)((nf + 1023) / 1024);
+        int fb = (int)((nf + 63) / 64);
         if (fb > WF_BLOCKS) fb = WF_BLOCKS;
         hipLaunchKernelGGL(wgrad_sum_kernel, dim3(fb), dim3(256), 0, st, slabs, n_slabs, nf, (const float*)nullptr, fsum,
                            (float*)nullptr, bias_slabs, db, Cout);

@@ -46,11 +46,11 @@ def main():
 
     def rec_f(ctx, *a):
         y = orig_f(ctx, *a)
-        fwd_calls[ctx.cfg[:8]] += 1
+        fwd_calls[ctx.cfg[:8] + (int(ctx.cfg[10]), int(ctx.cfg[11]))] += 1
         return y
 
     def rec_b(ctx, dy):
-        bwd_calls[(ctx.cfg[:8], bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]))] += 1
+        bwd_calls[(ctx.cfg[:8] + (int(ctx.cfg[10]), int(ctx.cfg[11])), bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]))] += 1
         return orig_b(ctx, dy)
 
     ops.ConvFn.forward, ops.ConvFn.backward = staticmethod(rec_f), staticmethod(rec_b)
@@ -63,25 +63,29 @@ def main():
     rows = []
     tot = collections.Counter()
     for cfg, cnt in fwd_calls.items():
-        N, H, W, Cin, Cout, KH, ups, slope = cfg
+        N, H, W, Cin, Cout, KH, ups, slope, pool, fold = cfg
         n_dx = sum(c for (cf, dx, dw), c in bwd_calls.items() if cf == cfg and dx)
         n_dw = sum(c for (cf, dx, dw), c in bwd_calls.items() if cf == cfg and dw)
-        sh = _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope)
+        sh = _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0)
         x = torch.randn(N, H >> ups, W >> ups, Cin, device=dev)
-        w = torch.randn(Cout, KH, KH, Cin, device=dev) * 0.05
-        y = torch.randn(N, H, W, Cout, device=dev)
-        dx = torch.empty(N, H, W, Cin, device=dev)
+        KF = KH + 1 if fold else KH
+        w = torch.randn(Cout, KF, KF, Cin, device=dev) * 0.05   # folded layout when fold
+        wplain = torch.randn(Cout, KH, KH, Cin, device=dev) * 0.05
+        y = torch.randn(N, H >> pool, W >> pool, Cout, device=dev)
+        lowdx = 1 if (ups and fold) else 0
+        dx = torch.empty(N, H >> lowdx, W >> lowdx, Cin, device=dev)
         ns = lib.gim_conv2d_wgrad_slabs(sh)
-        slabs = torch.empty(ns * Cout * KH * KH * Cin, device=dev)
+        slabs = torch.empty(ns * Cout * KF * KF * Cin, device=dev)
         dw = torch.empty(Cout * KH * KH * Cin, device=dev)
-        scr = torch.empty(512, device=dev)
+        scr = torch.empty(512 + Cout * KF * KF * Cin, device=dev)
+        foldmode = (2 if ups else 1) if fold else 0
         flops = 2.0 * N * H * W * Cout * Cin * KH * KH
         t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
         t_d = time_ms(lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
 
         def wg():
             lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st)
-            lib.gim_wgrad_finish(slabs.data_ptr(), None, ns, None, None, None, None, dw.data_ptr(), None, scr.data_ptr(), Cout, Cin, KH, st)
+            lib.gim_wgrad_finish(slabs.data_ptr(), None, ns, None, None, None, None, dw.data_ptr(), None, scr.data_ptr(), Cout, Cin, KH, foldmode, st)
         t_w = time_ms(wg) if n_dw else 0.0
         total = cnt * t_f + n_dx * t_d + n_dw * t_w
         tot["fwd"] += cnt * t_f
@@ -91,7 +95,7 @@ def main():
         rows.append((total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns))
     rows.sort(reverse=True)
     print("%-46s %4s %4s %4s %8s | %8s %6s | %8s %6s | %8s %6s %4s | %8s" %
-          ("N,H,W,Cin,Cout,K,ups,slope", "fwd", "dx", "dw", "GF", "fwd ms", "TF", "dgrad ms", "TF", "wgrad ms", "TF", "S", "tot ms"))
+          ("N,H,W,Cin,Cout,K,ups,slope,pool,fold", "fwd", "dx", "dw", "GF", "fwd ms", "TF", "dgrad ms", "TF", "wgrad ms", "TF", "S", "tot ms"))
     for total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns in rows:
         tf = lambda t: flops / t / 1e9 if t else 0.0  # noqa: E731
         print("%-46s %4d %4d %4d %8.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f %4d | %8.2f" %
