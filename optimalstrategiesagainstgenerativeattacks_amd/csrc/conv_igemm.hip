@@ -156,10 +156,8 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (v) {
                     const float* src = p.x + a_base[i] + (long long)((iy >> g.ups) * g.Win + (ix >> g.ups)) * p.Ca + c0 + aq;
-                    val = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = lrelu_f(val[e], p.pre_slope);
-                }
+                    val = *reinterpret_cast<const f32x4*>(src);  // raw: nothing may consume a loaded value before
+                }                                                // the MFMA block (it would force vmcnt(0) here)
                 ra[i] = val;
             }
         } else {
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
                     const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
                     const bool v = a_ok[i] && kf < p.Ktot && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
                     float val = 0.f;
-                    if (v) val = lrelu_f(p.x[a_base[i] + (long long)((iy >> g.ups) * g.Win + (ix >> g.ups)) * p.Ca + c], p.pre_slope);
+                    if (v) val = p.x[a_base[i] + (long long)((iy >> g.ups) * g.Win + (ix >> g.ups)) * p.Ca + c];
                     ra[i][e] = val;
                 }
             }
@@ -260,8 +258,12 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
 
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i)
-            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
+        for (int i = 0; i < A_ROWS; ++i) {
+            f32x4 val = ra[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = lrelu_f(val[e], p.pre_slope);  // fused activation, after the loads landed
+            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = val;
+        }
         if constexpr (BMODE == 0) {
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) {
@@ -426,13 +428,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (v) val = *reinterpret_cast<const f32x4*>(p.dy + (long long)m * p.Cout + co0 + ac);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ra[i][e] = lrelu_f(val[e], p.a_slope);
+                for (int e = 0; e < 4; ++e) ra[i][e] = val[e];
             } else {
-                ra[i][0] = v ? lrelu_f(p.dy[(long long)m * p.Cout + co0 + ac], p.a_slope) : 0.f;
-            }
-            if (do_bias) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) bsum[e] += ra[i][e];
+                float val = 0.f;
+                if (v) val = p.dy[(long long)m * p.Cout + co0 + ac];
+                ra[i][0] = val;
             }
         }
 #pragma unroll
@@ -448,13 +448,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (v) val = *reinterpret_cast<const f32x4*>(p.x + off);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[i][e] = lrelu_f(val[e], p.pre_slope);
+                for (int e = 0; e < 4; ++e) rb[i][e] = val[e];
             } else {
-                rb[i][0] = v ? lrelu_f(p.x[off], p.pre_slope) : 0.f;
+                float val = 0.f;
+                if (v) val = p.x[off];
+                rb[i][0] = val;
             }
         }
     };
+    // activations and the bias sums consume the loaded values here, after the MFMA block, never in load_tiles
     auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                ra[i][e] = lrelu_f(ra[i][e], p.a_slope);
+                if (do_bias) bsum[e] += ra[i][e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) rb[i][e] = lrelu_f(rb[i][e], p.pre_slope);
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int row = ak + i * A_RSTEP;
