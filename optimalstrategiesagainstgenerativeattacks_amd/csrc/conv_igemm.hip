@@ -88,9 +88,16 @@ struct ConvP {
 
 // GENF bit 0: generic K (channel count of the gathered tensor not a multiple of 16, or unaligned base)
 // GENF bit 1: (BMODE 1 only) scalar loads of the k-major weight tile (output channels not a multiple of 4)
+//
 // __launch_bounds__(256, 4): cap the allocation at 128 registers (accumulators included) so that 4 workgroups
 // (40 KB of LDS each at K step 16) share a CU: 4 waves per SIMD hide the global->LDS->MFMA latency of the
-// one-barrier-per-K-step pipeline better than 3 (no spills: 120-126 VGPRs).
+// one-barrier-per-K-step pipeline better than 3 (no spills: ~120 VGPRs).
+//
+// Address generation is kept off the critical path (PMC: at ~1 wave per SIMD the non-MFMA instruction stream, not
+// memory, bounded the mid-size layers): per thread and tile row ONE 32-bit element offset is computed up front;
+// per K step only a wave-uniform (tap, channel) offset advances - incrementally, no integer divisions - and the
+// per-row work is two adds, two compares and the load.  Loaded values are not touched until store_tiles (any
+// consumer would pull an s_waitcnt vmcnt(0) in front of the MFMA block).
 template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB>
 __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
@@ -124,9 +131,11 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     const int n0 = blockIdx.y * BN;
     const int arow = t / QPR, aq = (t % QPR) * 4;
     const int He = g.Hin << g.ups, We = g.Win << g.ups;  // extent of the (virtually upsampled) gathered image
+    const int KF2 = g.KF * g.KF;
 
+    // per-row constants of the A gather: pixel origin (for the bounds test) and element offset without the tap
     int a_oy[A_ROWS], a_ox[A_ROWS];
-    long long a_base[A_ROWS];
+    long long a_off[A_ROWS];
     bool a_ok[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -135,32 +144,89 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
         const int n = m >> (g.logH + g.logW);
         a_oy[i] = ((m >> g.logW) & (g.H - 1)) * g.s_in + g.off_y;
         a_ox[i] = (m & (g.W - 1)) * g.s_in + g.off_x;
-        a_base[i] = (long long)n * g.Hin * g.Win * p.Ca;
+        a_off[i] = (long long)n * g.Hin * g.Win * p.Ca + (GEN ? 0 : aq);
+        if (!g.ups) a_off[i] += ((long long)a_oy[i] * g.Win + a_ox[i]) * p.Ca;
     }
+    // per-thread constants of the B tile
+    long long b_off0[B_ROWS];
+    bool b_ok0[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+        const int row = arow + RP * i;
+        b_ok0[i] = row < BN && (n0 + row) < p.Cb;
+        b_off0[i] = (long long)(n0 + row) * KF2 * p.Cin_w + aq;
+    }
+    const int b4_krow = t / B_U, b4_col = (t % B_U) * 4;
+    const bool b4_cok = (n0 + b4_col) < p.Cb;  // Cb % 4 == 0 on the vector path: the whole quad is in range
 
     f32x4 ra[A_ROWS];
     f32x4 rb0[B_ROWS];
     float rb1[B_PER];
     f32x4 rb4[B_PER4];
 
+    // wave-uniform K position, advanced incrementally by load_tiles (fast path)
+    int k_c0 = 0, k_ta = 0, k_tb = 0;
+    auto seek = [&](int k0) {
+        const int tap = k0 / p.Ca;
+        k_c0 = k0 - tap * p.Ca;
+        k_ta = tap / g.Tw;
+        k_tb = tap - k_ta * g.Tw;
+    };
+
     auto load_tiles = [&](int k0) {
-        // ---- A: gathered activations ----
         if constexpr (!GEN) {
-            const int tap = k0 / p.Ca;
-            const int c0 = k0 - tap * p.Ca;
-            const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
+            const int ta = k_ta, tb = k_tb, c0 = k_c0;
+            const int wtap = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
+            // ---- A: gathered activations ----
+            const float* xa = p.x + ((long long)(ta * g.Win + tb) * p.Ca + c0);  // uniform part (ups == 0)
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
                 const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
                 const bool v = a_ok[i] && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (v) {
-                    const float* src = p.x + a_base[i] + (long long)((iy >> g.ups) * g.Win + (ix >> g.ups)) * p.Ca + c0 + aq;
-                    val = *reinterpret_cast<const f32x4*>(src);  // raw: nothing may consume a loaded value before
-                }                                                // the MFMA block (it would force vmcnt(0) here)
+                    const float* src = g.ups ? p.x + a_off[i] + (long long)((iy >> 1) * g.Win + (ix >> 1)) * p.Ca + c0
+                                             : xa + a_off[i];
+                    val = *reinterpret_cast<const f32x4*>(src);
+                }
                 ra[i] = val;
             }
+            // ---- B: weights ----
+            if constexpr (BMODE == 0) {
+                const float* wb = p.w + ((long long)wtap * p.Cin_w + c0);
+#pragma unroll
+                for (int i = 0; i < B_ROWS; ++i) {
+                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                    if (b_ok0[i]) val = *reinterpret_cast<const f32x4*>(wb + b_off0[i]);
+                    rb0[i] = val;
+                }
+            } else {
+                const float* wb = p.w + (((long long)c0 * KF2 + wtap) * p.Cin_w + n0);
+                if constexpr (BSCALAR) {
+#pragma unroll
+                    for (int i = 0; i < B_PER; ++i) {
+                        const int idx = t + 256 * i;
+                        const int krow = idx / BN, col = idx % BN;
+                        rb1[i] = (n0 + col) < p.Cb ? wb[(long long)krow * KF2 * p.Cin_w + col] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < B_PER4; ++i) {
+                        const int krow = b4_krow + i * B_RSTEP;
+                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        if (krow < KB && b4_cok) val = *reinterpret_cast<const f32x4*>(wb + (long long)krow * KF2 * p.Cin_w + b4_col);
+                        rb4[i] = val;
+                    }
+                }
+            }
+            // advance the uniform K position by one step (Ca % KB == 0 on this path)
+            k_c0 += KB;
+            if (k_c0 == p.Ca) {
+                k_c0 = 0;
+                if (++k_tb == g.Tw) { k_tb = 0; ++k_ta; }
+            }
         } else {
+            // ---- generic K: per-element (tap, channel) decode; small layers only (Cin in {1,2,3,6}, Cout = 3) ----
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
 #pragma unroll
@@ -169,32 +235,22 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
                     const int tap = kf / p.Ca;
                     const int c = kf - tap * p.Ca;
                     const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
-                    const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
+                    const int iy = (a_oy[i] + ta), ix = (a_ox[i] + tb);
                     const bool v = a_ok[i] && kf < p.Ktot && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
                     float val = 0.f;
-                    if (v) val = p.x[a_base[i] + (long long)((iy >> g.ups) * g.Win + (ix >> g.ups)) * p.Ca + c];
+                    if (v) {
+                        const long long off = g.ups ? a_off[i] + (long long)((iy >> 1) * g.Win + (ix >> 1)) * p.Ca + c
+                                                    : a_off[i] + (long long)(ta * g.Win + tb) * p.Ca + c;
+                        val = p.x[off];
+                    }
                     ra[i][e] = val;
                 }
             }
-        }
-        // ---- B: weights; tap (ta, tb) of the loop maps to tap (wa, wb) of the stored tensor ----
-        if constexpr (BMODE == 0) {
-            int wtap_u = 0, c0_u = 0;
-            if constexpr (!GEN) {
-                const int tap = k0 / p.Ca;
-                c0_u = k0 - tap * p.Ca;
-                const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
-                wtap_u = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
-            }
+            if constexpr (BMODE == 0) {
 #pragma unroll
-            for (int i = 0; i < B_ROWS; ++i) {
-                const int row = arow + RP * i;
-                const int co = n0 + row;
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (row < BN && co < p.Cb) {
-                    if constexpr (!GEN) {
-                        val = *reinterpret_cast<const f32x4*>(p.w + ((long long)co * g.KF * g.KF + wtap_u) * p.Cin_w + c0_u + aq);
-                    } else {
+                for (int i = 0; i < B_ROWS; ++i) {
+                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                    if (b_ok0[i]) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int kf = k0 + aq + e;
@@ -202,55 +258,41 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
                                 const int tap = kf / p.Ca, c = kf - tap * p.Ca;
                                 const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
                                 const int wt = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
-                                val[e] = p.w[((long long)co * g.KF * g.KF + wt) * p.Cin_w + c];
+                                val[e] = p.w[b_off0[i] - aq + (long long)wt * p.Cin_w + c];
                             }
                         }
                     }
-                }
-                rb0[i] = val;
-            }
-        } else {
-            int wtap_u = 0, c0_u = 0;
-            if constexpr (!GEN) {
-                const int tap = k0 / p.Ca;
-                c0_u = k0 - tap * p.Ca;
-                const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
-                wtap_u = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
-            }
-            auto wrow = [&](int krow, bool& v) -> long long {  // offset of weight row (channel ca, mapped tap)
-                int wt = wtap_u, ca = c0_u + krow;
-                if constexpr (GEN) {
-                    const int kf = k0 + krow;
-                    const int tap = kf / p.Ca;
-                    ca = kf - tap * p.Ca;
-                    const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
-                    wt = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
-                    v = v && kf < p.Ktot;
-                }
-                return ((long long)ca * g.KF * g.KF + wt) * p.Cin_w;
-            };
-            if constexpr (BSCALAR) {
-#pragma unroll
-                for (int i = 0; i < B_PER; ++i) {
-                    const int idx = t + 256 * i;
-                    const int krow = idx / BN, col = idx % BN;
-                    bool v = true;
-                    const long long ro = wrow(krow, v);
-                    const int ci = n0 + col;
-                    v = v && ci < p.Cb;
-                    rb1[i] = v ? p.w[ro + ci] : 0.f;
+                    rb0[i] = val;
                 }
             } else {
+                auto wrow = [&](int krow, bool& v) -> long long {  // offset of weight row (channel ca, mapped tap)
+                    const int kf = k0 + krow;
+                    const int tap = kf / p.Ca;
+                    const int ca = kf - tap * p.Ca;
+                    const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
+                    const int wt = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
+                    v = v && kf < p.Ktot;
+                    return ((long long)ca * KF2 + wt) * p.Cin_w;
+                };
+                if constexpr (BSCALAR) {
 #pragma unroll
-                for (int i = 0; i < B_PER4; ++i) {
-                    const int krow = t / B_U + i * B_RSTEP, col = (t % B_U) * 4;
-                    bool v = krow < KB;
-                    const long long ro = wrow(krow, v);
-                    const int ci = n0 + col;
-                    v = v && ci < p.Cb;  // Cb % 4 == 0 on this path: the whole quad is in range
-                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (v) val = *reinterpret_cast<const f32x4*>(p.w + ro + ci);
-                    rb4[i] = val;
+                    for (int i = 0; i < B_PER; ++i) {
+                        const int idx = t + 256 * i;
+                        const int krow = idx / BN, col = idx % BN;
+                        bool v = (n0 + col) < p.Cb;
+                        const long long ro = wrow(krow, v);
+                        rb1[i] = v ? p.w[ro + n0 + col] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < B_PER4; ++i) {
+                        const int krow = b4_krow + i * B_RSTEP;
+                        bool v = krow < KB && b4_cok;
+                        const long long ro = wrow(krow, v);
+                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        if (v) val = *reinterpret_cast<const f32x4*>(p.w + ro + n0 + b4_col);
+                        rb4[i] = val;
+                    }
                 }
             }
         }
@@ -277,8 +319,8 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
             } else {
 #pragma unroll
                 for (int i = 0; i < B_PER4; ++i) {
-                    const int krow = t / B_U + i * B_RSTEP, col = (t % B_U) * 4;
-                    if (krow < KB) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + krow * BN + col]) = rb4[i];
+                    const int krow = b4_krow + i * B_RSTEP;
+                    if (krow < KB) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + krow * BN + b4_col]) = rb4[i];
                 }
             }
         }
@@ -298,6 +340,7 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     const int nk_all = (p.Ktot + KB - 1) / KB;
     const int ks0 = kslice * p.kper;
     const int nk = min(nk_all, ks0 + p.kper);
+    if constexpr (!GEN) seek(ks0 * KB);
     load_tiles(ks0 * KB);
     store_tiles(ks0 & 1);
     __syncthreads();
@@ -651,15 +694,20 @@ static Geo geo_pc(const gim_conv_shape* s, int kind) {
 // K step 32 measured SLOWER on MI355X (104 vs 111 episodes/s: 73 KB of LDS per workgroup leaves 2 waves per
 // SIMD instead of 3); kept as an opt-in for A/B runs.
 static const bool g_force_kb16 = getenv("GIM_CONV_KB32") == nullptr;
+// (A prefetch distance of 2 K steps, with a second register stage, was measured and brought nothing - 175 vs 177
+// episodes/s: the mid-size layers were bound by address arithmetic, not by load latency.)
 
-// Small-M layers (4x4x512 maps, the decoder head, linears on <= 240 rows) have too few output tiles to fill
-// 256 CUs and are bound by the latency of their long K loop: slice K over grid.z until there is about one
-// workgroup per CU, each keeping >= 8 K-steps.
+// Layers whose output tiles do not fill the chip (8x8 and smaller maps, the decoder head, linears) are sliced
+// along K over grid.z.  Measured sweep on MI355X (profiles/r01_ksplit_sweep.txt): best when the launch has about
+// two workgroups per CU (~512); beyond 6 slices the float atomics of the combine cost more than they buy.
+static const int g_force_ksplit = getenv("GIM_CONV_KSPLIT") ? atoi(getenv("GIM_CONV_KSPLIT")) : 0;  // experiments
+
 static int plan_ksplit(long long wgs, int nk) {
-    if (wgs >= 192 || nk < 16) return 1;
-    long long ks = (256 + wgs - 1) / wgs;
+    if (g_force_ksplit > 0) return g_force_ksplit > nk ? nk : g_force_ksplit;
+    if (wgs >= 448 || nk < 16) return 1;
+    long long ks = (512 + wgs / 2) / wgs;
     if (ks > nk / 8) ks = nk / 8;
-    if (ks > 32) ks = 32;
+    if (ks > 6) ks = 6;
     return ks < 1 ? 1 : (int)ks;
 }
 
