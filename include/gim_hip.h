@@ -83,10 +83,11 @@ int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* bias_
  *   else          : dw = g / sigma - (<g, w> / sigma^2) u v^T (autograd through torch spectral_norm's
  *                   weight = weight_orig / (u^T W v) with u, v constants).
  * u [Cout]; v [Cin*KH*KW] in the REFERENCE's flattening order (ci, kh, kw).  scratch: >= 512 floats, plus
- * Cout*(KH+1)^2*Cin floats when fold != 0. */
+ * Cout*(KH+1)^2*Cin floats when fold != 0.  acc_dw / acc_db (may be NULL): ADD the results into these buffers
+ * (the optimizer's flat gradient bucket) instead of returning them in dw / db (dw then is scratch). */
 int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int n_slabs, const float* w, const float* sigma,
                      const float* u, const float* v, float* dw, float* db, float* scratch, int Cout, int Cin, int KH,
-                     int fold, void* stream);
+                     int fold, float* acc_dw, float* acc_db, void* stream);
 
 /* One power iteration of torch.nn.utils.spectral_norm (n_power_iterations=1, eps=1e-12, dim=0):
  *   v <- normalize(W^T u); u <- normalize(W v); sigma = u^T W v.       (training = 1)

@@ -27,7 +27,7 @@ SIGNATURES = {
     "gim_conv2d_dgrad": [P, P, P, P, P, SP, P],
     "gim_conv2d_wgrad_slabs": [SP],
     "gim_conv2d_wgrad": [P, P, P, P, c_int, SP, P],
-    "gim_wgrad_finish": [P, P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "gim_wgrad_finish": [P, P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P],
     "gim_conv2d_fold_weights": [P, P, c_int, c_int, c_int, P],
     "gim_spectral_sigma": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_spectral_sigma_batched": [P, c_int, P, c_int, P, c_int, P, c_int, P],

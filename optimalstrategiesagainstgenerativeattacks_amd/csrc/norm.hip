@@ -5,9 +5,10 @@
 // (defined behaviour for zero-variance input).
 #include "common.h"
 
-template <int VEC>
+// CB = channels per workgroup (64, or 4 for the 1/3-channel image-sized maps: then 64 thread groups split H*W)
+template <int VEC, int CB>
 struct NormCfg {
-    static constexpr int CL = 64 / VEC;   // lanes along channels
+    static constexpr int CL = CB / VEC;   // lanes along channels
     static constexpr int HG = 256 / CL;   // groups along H*W
 };
 
@@ -31,31 +32,31 @@ __device__ __forceinline__ void st_vec(float* p, const float (&v)[VEC]) {
 }
 
 // reduce VEC values per thread across the HG groups; result broadcast to every thread of a channel lane
-template <int VEC>
+template <int VEC, int CB>
 __device__ __forceinline__ void group_reduce(float (&v)[VEC], float* red, int cl, int hg) {
-    constexpr int HG = NormCfg<VEC>::HG;
+    constexpr int HG = NormCfg<VEC, CB>::HG;
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) red[hg * 64 + cl * VEC + e] = v[e];
+    for (int e = 0; e < VEC; ++e) red[hg * CB + cl * VEC + e] = v[e];
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         float s = 0.f;
-        for (int g = 0; g < HG; ++g) s += red[g * 64 + cl * VEC + e];
+        for (int g = 0; g < HG; ++g) s += red[g * CB + cl * VEC + e];
         v[e] = s;
     }
 }
 
-template <int VEC>
+template <int VEC, int CB>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        float* __restrict__ y, float* __restrict__ stats, int HW, int C, int mode,
                                                        float eps) {
-    constexpr int CL = NormCfg<VEC>::CL, HG = NormCfg<VEC>::HG;
-    __shared__ float red[HG * 64];
+    constexpr int CL = NormCfg<VEC, CB>::CL, HG = NormCfg<VEC, CB>::HG;
+    __shared__ float red[HG * CB];
     const int n = blockIdx.y;
     const int cl = threadIdx.x % CL, hg = threadIdx.x / CL;
-    const int c = blockIdx.x * 64 + cl * VEC;
+    const int c = blockIdx.x * CB + cl * VEC;
     const bool ok = c < C;
     const float* xb = x + (long long)n * HW * C + c;
     float mean[VEC], ssq[VEC];
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < VEC; ++e) mean[e] += v[e];
         }
-    group_reduce<VEC>(mean, red, cl, hg);
+    group_reduce<VEC, CB>(mean, red, cl, hg);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         mean[e] /= (float)HW;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
                 ssq[e] += d * d;
             }
         }
-    group_reduce<VEC>(ssq, red, cl, hg);
+    group_reduce<VEC, CB>(ssq, red, cl, hg);
     if (!ok) return;
     float invd[VEC], sc[VEC], sh[VEC];
 #pragma unroll
@@ -126,16 +127,16 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
     }
 }
 
-template <int VEC>
+template <int VEC, int CB>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ scale, const float* __restrict__ stats,
                                                        float* __restrict__ dx, float* __restrict__ dscale_nc,
                                                        float* __restrict__ dshift_nc, int HW, int C, int mode) {
-    constexpr int CL = NormCfg<VEC>::CL, HG = NormCfg<VEC>::HG;
-    __shared__ float red[HG * 64];
+    constexpr int CL = NormCfg<VEC, CB>::CL, HG = NormCfg<VEC, CB>::HG;
+    __shared__ float red[HG * CB];
     const int n = blockIdx.y;
     const int cl = threadIdx.x % CL, hg = threadIdx.x / CL;
-    const int c = blockIdx.x * 64 + cl * VEC;
+    const int c = blockIdx.x * CB + cl * VEC;
     const bool ok = c < C;
     const long long off = (long long)n * HW * C + c;
     float mean[VEC], invd[VEC], c2[VEC], sc[VEC], s1[VEC], s2[VEC];
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
                 s2[e] += g[e] * ((v[e] - mean[e]) * invd[e]);
             }
         }
-    group_reduce<VEC>(s1, red, cl, hg);
-    group_reduce<VEC>(s2, red, cl, hg);
+    group_reduce<VEC, CB>(s1, red, cl, hg);
+    group_reduce<VEC, CB>(s2, red, cl, hg);
     if (!ok) return;
     if (hg == 0) {
 #pragma unroll
@@ -191,10 +192,11 @@ extern "C" int gim_norm_fwd(const float* x, const float* scale, const float* shi
                             float* stats, int N, int HW, int C, int mode, float eps, void* stream) {
     GIM_CHECK_ARG(x && scale && shift && y && stats, "norm_fwd: null pointer");
     GIM_CHECK_ARG(N > 0 && HW > 0 && C > 0 && (mode == 0 || mode == 1), "norm_fwd: bad dims");
-    dim3 g((C + 63) / 64, N);
     const bool vec = (C % 4 == 0) && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15);
-    if (vec) hipLaunchKernelGGL(norm_fwd_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, y, stats, HW, C, mode, eps);
-    else hipLaunchKernelGGL(norm_fwd_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, y, stats, HW, C, mode, eps);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL((norm_fwd_kernel<4, 64>), dim3((C + 63) / 64, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps);
+    else if (C <= 4) hipLaunchKernelGGL((norm_fwd_kernel<1, 4>), dim3(1, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps);
+    else hipLaunchKernelGGL((norm_fwd_kernel<1, 64>), dim3((C + 63) / 64, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps);
     return gim_check_launch("gim_norm_fwd");
 }
 
@@ -202,9 +204,10 @@ extern "C" int gim_norm_bwd(const float* dy, const float* x, const float* scale,
                             float* dscale_nc, float* dshift_nc, int N, int HW, int C, int mode, void* stream) {
     GIM_CHECK_ARG(dy && x && scale && stats && dx && dscale_nc && dshift_nc, "norm_bwd: null pointer");
     GIM_CHECK_ARG(N > 0 && HW > 0 && C > 0 && (mode == 0 || mode == 1), "norm_bwd: bad dims");
-    dim3 g((C + 63) / 64, N);
     const bool vec = (C % 4 == 0) && !(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15);
-    if (vec) hipLaunchKernelGGL(norm_bwd_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, dy, x, scale, stats, dx, dscale_nc, dshift_nc, HW, C, mode);
-    else hipLaunchKernelGGL(norm_bwd_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, dy, x, scale, stats, dx, dscale_nc, dshift_nc, HW, C, mode);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL((norm_bwd_kernel<4, 64>), dim3((C + 63) / 64, N), dim3(256), 0, st, dy, x, scale, stats, dx, dscale_nc, dshift_nc, HW, C, mode);
+    else if (C <= 4) hipLaunchKernelGGL((norm_bwd_kernel<1, 4>), dim3(1, N), dim3(256), 0, st, dy, x, scale, stats, dx, dscale_nc, dshift_nc, HW, C, mode);
+    else hipLaunchKernelGGL((norm_bwd_kernel<1, 64>), dim3((C + 63) / 64, N), dim3(256), 0, st, dy, x, scale, stats, dx, dscale_nc, dshift_nc, HW, C, mode);
     return gim_check_launch("gim_norm_bwd");
 }

@@ -125,13 +125,13 @@ extern "C" int gim_spectral_sigma(const float* w, float* u, float* v, float* sig
 __global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* __restrict__ slabs, int n_slabs, long long n,
                                                         const float* __restrict__ w, float* __restrict__ dw,
                                                         float* __restrict__ partial, const float* __restrict__ bias_slabs,
-                                                        float* __restrict__ db, int Cout) {
+                                                        float* __restrict__ db, int Cout, int acc_dw, int acc_db) {
     __shared__ float red[4];
     __shared__ float part[4][64];
     float dot = 0.f;
     if (db) {
         for (int c = blockIdx.x * 256 + threadIdx.x; c < Cout; c += gridDim.x * 256) {
-            float g = 0.f;
+            float g = acc_db ? db[c] : 0.f;
             for (int s = 0; s < n_slabs; ++s) g += bias_slabs[(long long)s * Cout + c];
             db[c] = g;
         }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* __restrict_
         __syncthreads();
         if (sg == 0 && i < n) {
             g = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
-            dw[i] = g;
+            dw[i] = acc_dw ? dw[i] + g : g;
             if (w) dot += g * w[i];
         }
         __syncthreads();
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void wgrad_unfold_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_sn_apply_kernel(float* __restrict__ dw, const float* __restrict__ partial, int n_part,
+__global__ __launch_bounds__(256) void wgrad_sn_apply_kernel(const float* __restrict__ g, float* __restrict__ dw, int accumulate,
+                                                             const float* __restrict__ partial, int n_part,
                                                              const float* __restrict__ sigma, const float* __restrict__ u,
                                                              const float* __restrict__ v, long long n, int Cin, int T) {
     __shared__ float red[4];
@@ -214,15 +215,16 @@ __global__ __launch_bounds__(256) void wgrad_sn_apply_kernel(float* __restrict__
         const int co = (int)(i / K);
         const int p = (int)(i - (long long)co * K);
         const int tap = p / Cin, ci = p - tap * Cin;
-        dw[i] = dw[i] * inv - coef * u[co] * v[ci * T + tap];
+        const float val = g[i] * inv - coef * u[co] * v[ci * T + tap];
+        dw[i] = accumulate ? dw[i] + val : val;
     }
 }
 
 extern "C" int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int n_slabs, const float* w, const float* sigma,
                                 const float* u, const float* v, float* dw, float* db, float* scratch, int Cout, int Cin, int KH,
-                                int fold, void* stream) {
+                                int fold, float* acc_dw, float* acc_db, void* stream) {
     GIM_CHECK_ARG(slabs && dw && n_slabs > 0, "wgrad_finish: bad args");
-    GIM_CHECK_ARG(!db || bias_slabs, "wgrad_finish: db needs bias_slabs");
+    GIM_CHECK_ARG((!db && !acc_db) || bias_slabs, "wgrad_finish: db needs bias_slabs");
     GIM_CHECK_ARG(!sigma || (w && u && v && scratch), "wgrad_finish: spectral form needs w, u, v, scratch");
     GIM_CHECK_ARG(fold >= 0 && fold <= 2 && (!fold || scratch), "wgrad_finish: bad fold / missing scratch");
     hipStream_t st = (hipStream_t)stream;
@@ -233,9 +235,13 @@ extern "C" int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int
     if (blocks < 1) blocks = 1;
     int sblocks = (int)((n + 63) / 64);  // wgrad_sum_kernel: 64 elements per block pass
     if (sblocks > WF_BLOCKS) sblocks = WF_BLOCKS;
+    float* bias_out = acc_db ? acc_db : db;
+    const int bias_acc = acc_db ? 1 : 0;
+    // the plain (no sigma, no fold) form can sum straight into the accumulation target
+    const bool direct = !sigma && !fold && acc_dw;
     if (fold == 0) {
-        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(sblocks), dim3(256), 0, st, slabs, n_slabs, n, sigma ? w : nullptr, dw,
-                           sigma ? scratch : nullptr, bias_slabs, db, Cout);
+        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(sblocks), dim3(256), 0, st, slabs, n_slabs, n, sigma ? w : nullptr,
+                           direct ? acc_dw : dw, sigma ? scratch : nullptr, bias_slabs, bias_out, Cout, direct ? 1 : 0, bias_acc);
         blocks = sblocks;  // number of <g, w> partials for the spectral apply
     } else {
         // 1) sum the slabs (folded layout) into scratch[512 ...], bias on the way; 2) un-fold into dw (+ <g, w>)
@@ -244,12 +250,16 @@ extern "C" int gim_wgrad_finish(const float* slabs, const float* bias_slabs, int
         int fb = (int)((nf + 63) / 64);
         if (fb > WF_BLOCKS) fb = WF_BLOCKS;
         hipLaunchKernelGGL(wgrad_sum_kernel, dim3(fb), dim3(256), 0, st, slabs, n_slabs, nf, (const float*)nullptr, fsum,
-                           (float*)nullptr, bias_slabs, db, Cout);
+                           (float*)nullptr, bias_slabs, bias_out, Cout, 0, bias_acc);
         hipLaunchKernelGGL(wgrad_unfold_kernel, dim3(blocks), dim3(256), 0, st, fsum, sigma ? w : nullptr, dw,
                            sigma ? scratch : nullptr, Cout, Cin, KH, fold);
     }
-    if (sigma)
-        hipLaunchKernelGGL(wgrad_sn_apply_kernel, dim3(blocks), dim3(256), 0, st, dw, scratch, blocks, sigma, u, v, n, Cin, T);
+    if (sigma) {
+        hipLaunchKernelGGL(wgrad_sn_apply_kernel, dim3(blocks), dim3(256), 0, st, dw, acc_dw ? acc_dw : dw, acc_dw ? 1 : 0, scratch,
+                           blocks, sigma, u, v, n, Cin, T);
+    } else if (acc_dw && !direct) {
+        GIM_CHECK_ARG(false, "wgrad_finish: acc_dw without sigma is only supported for fold == 0");
+    }
     return gim_check_launch("gim_wgrad_finish");
 }
 

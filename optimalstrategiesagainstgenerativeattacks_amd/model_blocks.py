@@ -110,13 +110,27 @@ class SNConv2d(nn.Module):
         self.register_buffer("weight_v", v)
 
         self._sn_queue = collections.deque()  # (sigma, u, v) triples precomputed by an SNPlan round
+        self._fold_cache = (None, None)       # ((storage, version, optimizer epoch), folded weights F)
+
+    def folded(self):
+        """The (k+1)^2-tap folded weights for the pool / sub-pixel forms, recomputed only when weight_orig changed
+        (autograd version counter for torch-side writes, optim.weights_epoch() for the fused Adam kernel)."""
+        from . import optim
+        w = self.weight_orig
+        key = (w.data_ptr(), w._version, optim.weights_epoch())
+        if self._fold_cache[0] != key:
+            with torch.no_grad():
+                f = ops._folded(ops.weight_phys(w), self.out_channels, self.in_channels, self.kernel_size)
+            self._fold_cache = (key, f)
+        return self._fold_cache[1]
 
     def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False):
         if self._sn_queue:
             sigma, u_s, v_s = self._sn_queue.popleft()
         else:
             sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
-        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups)
+        wf = self.folded() if (pool or (ups and self.kernel_size > 1)) else None
+        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d (spectral norm)" % (self.in_channels, self.out_channels, self.kernel_size)

@@ -81,7 +81,7 @@ class ConvFn(Function):
     res_ups: the residual is stored at half the output resolution."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups):
+    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf=None):
         lib = _lib.load()
         x = _req(x, "x")
         wp = weight_phys(_req_w(w))
@@ -100,16 +100,18 @@ class ConvFn(Function):
         y = torch.empty((N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         if res is not None:
             res = _req(res, "res")
-        wk = _folded(wp, Cout, Cin, KH) if fold else wp
+        if fold and wf is None:
+            wf = _folded(wp, Cout, Cin, KH)
+        wk = wf if fold else wp
         check(lib.gim_conv2d_fwd(_p(x), _p(wk), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd")
-        ctx.save_for_backward(x, w, sigma, u_s, v_s)
+        ctx.save_for_backward(x, w, sigma, u_s, v_s, wf if fold else None, bias)
         ctx.cfg = (N, H, W, Cin, Cout, KH, ups, pre_slope, bias is not None, res is not None, bool(pool), fold, bool(res_ups))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, w, sigma, u_s, v_s = ctx.saved_tensors
+        x, w, sigma, u_s, v_s, wf, bias = ctx.saved_tensors
         N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = ctx.cfg
         dy = _req(dy, "dy")
         wp = weight_phys(w)
@@ -120,7 +122,7 @@ class ConvFn(Function):
         mask = x if pre_slope != 1.0 else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wk = _folded(wp, Cout, Cin, KH) if fold else wp
+            wk = wf if fold else wp
             if ups and not fold:
                 dxu = torch.empty((N, H, W, Cin), device=dev, dtype=torch.float32)
                 check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), None, _p(dxu), sh, st), "conv2d_dgrad")
@@ -138,9 +140,14 @@ class ConvFn(Function):
             KFF = (KH + 1) * (KH + 1) * Cin if fold else K
             dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
             slab_bias = want_b and not (fold and ups)  # the role-swapped sub-pixel wgrad does not stream dy as its A operand
-            if want_b:
+            # Megatron-style direct accumulation: when the parameter's .grad already exists as a dense buffer in the
+            # weight's own memory order (FusedAdam's flat gradient bucket) and no higher-order graph is being built,
+            # the finish kernels ADD into it and autograd gets None (no AccumulateGrad add kernel per parameter).
+            acc_w = _grad_target(w) if (sigma is not None or not fold) and not torch.is_grad_enabled() else None
+            acc_b = _grad_target(bias) if (slab_bias and acc_w is not None) else None
+            if want_b and acc_b is None:
                 db = torch.empty(Cout, device=dev, dtype=torch.float32)
-            if ns == 1 and sigma is None and not fold:
+            if ns == 1 and sigma is None and not fold and acc_w is None:
                 check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(dwp), _p(db) if slab_bias else None, 1, sh, st), "conv2d_wgrad")
             else:
                 slabs = torch.empty(ns * Cout * KFF, device=dev, dtype=torch.float32)
@@ -148,12 +155,13 @@ class ConvFn(Function):
                 scratch = torch.empty(512 + (Cout * KFF if fold else 0), device=dev, dtype=torch.float32)
                 check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(slabs), _p(bslabs), ns, sh, st), "conv2d_wgrad")
                 check(lib.gim_wgrad_finish(_p(slabs), _p(bslabs), ns, _p(wp), _p(sigma), _p(u_s), _p(v_s), _p(dwp),
-                                           _p(db) if slab_bias else None, _p(scratch), Cout, Cin, KH,
-                                           (2 if ups else 1) if fold else 0, st), "wgrad_finish")
+                                           _p(db) if (slab_bias and acc_b is None) else None, _p(scratch), Cout, Cin, KH,
+                                           (2 if ups else 1) if fold else 0, _p(acc_w), _p(acc_b), st), "wgrad_finish")
             if want_b and not slab_bias:
                 scr = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
                 check(lib.gim_colsum(_p(dy), _p(db), _p(scr), Mo, Cout, st), "colsum")
-            dw = dwp.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2) if w.dim() == 4 else dwp.view(Cout, Cin)
+            if acc_w is None:
+                dw = dwp.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2) if w.dim() == 4 else dwp.view(Cout, Cin)
         elif want_b:
             db = torch.empty(Cout, device=dev, dtype=torch.float32)
             scratch = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
@@ -164,7 +172,18 @@ class ConvFn(Function):
                 check(lib.gim_upsample2x_bwd(_p(dy), None, 1.0, _p(dres), N, H >> 1, W >> 1, Cout, st), "upsample2x_bwd")
             else:
                 dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+
+
+def _grad_target(p):
+    """The parameter's existing .grad as a flat buffer in the parameter's own memory order, or None."""
+    if p is None:
+        return None
+    g = p.grad
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or g.shape != p.shape:
+        return None
+    gp = g.permute(0, 2, 3, 1) if g.dim() == 4 else g
+    return gp if gp.is_contiguous() else None
 
 
 def _req_w(w):
@@ -173,14 +192,14 @@ def _req_w(w):
     return w
 
 
-def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0, pool=False, res_ups=False):
-    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups)
+def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, wf=None):
+    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf)
 
 
 def linear(x, w, bias=None, pre_slope=1.0):
     """nn.Linear on the last dim (optionally with a fused LeakyReLU on the input)."""
     shp = x.shape
-    y = ConvFn.apply(x.reshape(-1, shp[-1]), w, bias, None, None, None, None, 0, pre_slope, False, False)
+    y = ConvFn.apply(x.reshape(-1, shp[-1]), w, bias, None, None, None, None, 0, pre_slope, False, False, None)
     return y.view(*shp[:-1], w.shape[0])
 
 

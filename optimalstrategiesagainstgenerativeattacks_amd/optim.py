@@ -35,6 +35,15 @@ def _view_like(flat_slice, ref):
     return flat_slice.view(ref.shape)
 
 
+_WEIGHTS_EPOCH = 0
+
+
+def weights_epoch():
+    """Bumped by every FusedAdam.step(): the Adam kernel writes parameters through raw pointers, which torch's
+    version counters do not see; caches derived from weights (folded conv weights) key on this."""
+    return _WEIGHTS_EPOCH
+
+
 def _pad(n, align=64):
     return (n + align - 1) // align * align
 
@@ -167,6 +176,8 @@ class FusedAdam(torch.optim.Optimizer):
                                 g0["betas"][0], g0["betas"][1], g0["eps"], scale, self._step_dev.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream), "adam_step")
         self._host_step += 1
+        global _WEIGHTS_EPOCH
+        _WEIGHTS_EPOCH += 1
 
     # ------------------------------------------------------------------ checkpoint format
     def state_dict(self):

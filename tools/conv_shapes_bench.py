@@ -85,7 +85,7 @@ def main():
 
         def wg():
             lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st)
-            lib.gim_wgrad_finish(slabs.data_ptr(), None, ns, None, None, None, None, dw.data_ptr(), None, scr.data_ptr(), Cout, Cin, KH, foldmode, st)
+            lib.gim_wgrad_finish(slabs.data_ptr(), None, ns, None, None, None, None, dw.data_ptr(), None, scr.data_ptr(), Cout, Cin, KH, foldmode, None, None, st)
         t_w = time_ms(wg) if n_dw else 0.0
         total = cnt * t_f + n_dx * t_d + n_dw * t_w
         tot["fwd"] += cnt * t_f
