@@ -49,6 +49,18 @@ def algo_gflop_per_episode(w, m, n, k):
     return 3 * F_im + F_auG + (2 * n * u["E"] + H) + 3 * F_auD
 
 
+def measured_hbm_traffic(workload, B):
+    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE; profiles/*hbm_traffic*.json).  bench.py cannot run the profiler on itself, so this
+    is the last profiled value for the workload, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s_B%d.json" % (workload, B))
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_step"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def synthetic_batch(B, m, n, k, C, S, device, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     mk = lambda t: (torch.rand((B, t, C, S, S), generator=g) * 2 - 1).to(device)  # noqa: E731  dataset range is [-1, 1]
@@ -209,7 +221,8 @@ def main():
                                    "G step + D step + 2 Adam updates per step, reg_param=0" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B),
                        "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": measured_hbm_traffic(args.workload, B) if world == 1 else None, "traffic_unit": "HBM bytes/step (rocprofv3 PMC, profiles/)",
                          "algo_gflop_per_episode": round(algo, 1), "device_ms_per_step": round(dev_ms / args.steps, 3)},
             "final_losses": {"g": round(g_loss, 5), "d": round(d_loss, 5)},
         }
