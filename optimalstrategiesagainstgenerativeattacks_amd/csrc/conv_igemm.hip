@@ -84,6 +84,8 @@ struct ConvP {
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
     int kper;     // K-steps per slice
+    int gx, gy;   // tiles along M / N
+    int xcd;      // 1: XCD-aware tile order over a 1-D grid (see the kernel)
 };
 
 // GENF bit 0: generic K (channel count of the gathered tensor not a multiple of 16, or unaligned base)
@@ -127,11 +129,24 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
         kslice = blockIdx.z >> 2;
     }
     const int t = threadIdx.x;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  XCD-aware order: XCD x
+    // walks a contiguous chunk of M tiles, and for each M tile all its N tiles back to back, so the activation
+    // tile (shared by the N tiles) and the halo rows (shared by neighbouring M tiles) are re-read from that XCD's
+    // own L2 instead of HBM.  Placement only affects speed, never results.
+    int mt = blockIdx.x, nt = blockIdx.y;
+    if (p.xcd) {
+        const int chunk = (p.gx + 7) >> 3;
+        const int x = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+        mt = x * chunk + sidx / p.gy;
+        nt = sidx - (sidx / p.gy) * p.gy;
+        if (mt >= p.gx || sidx >= chunk * p.gy) return;  // padding blocks of the rounded-up grid
+    }
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
     const int arow = t / QPR, aq = (t % QPR) * 4;
     const int He = g.Hin << g.ups, We = g.Win << g.ups;  // extent of the (virtually upsampled) gathered image
     const int KF2 = g.KF * g.KF;
+    const bool act = p.pre_slope != 1.0f;
 
     // per-row constants of the A gather: pixel origin (for the bounds test) and element offset without the tap
     int a_oy[A_ROWS], a_ox[A_ROWS];
@@ -302,8 +317,10 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             f32x4 val = ra[i];
+            if (act) {  // fused leaky-relu (0 < slope < 1: max(x, slope*x)), after the loads landed; wave-uniform branch
 #pragma unroll
-            for (int e = 0; e < 4; ++e) val[e] = lrelu_f(val[e], p.pre_slope);  // fused activation, after the loads landed
+                for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], val[e] * p.pre_slope);
+            }
             *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = val;
         }
         if constexpr (BMODE == 0) {
@@ -390,15 +407,17 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m >= p.M) continue;
-                const int n = m >> (g.logH + g.logW);
-                const int oy = ((m >> g.logW) & (g.H - 1)) * g.os + g.py;
-                const int ox = (m & (g.W - 1)) * g.os + g.px;
-                const long long o = (((long long)n * Ho + oy) * Wo + ox) * p.Cb + co;
-                float v = acc[i][j][e] * scale + bv;
-                if (p.res && first) {
-                    const long long ro = p.res_ups ? (((long long)n * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * p.Cb + co : o;
-                    v += p.res[ro];
+                long long o = (long long)m * p.Cb + co;  // os == 1: the logical pixel index is the stored one
+                long long ro = o;
+                if (g.os != 1 || p.res_ups) {  // wave-uniform
+                    const int n = m >> (g.logH + g.logW);
+                    const int oy = ((m >> g.logW) & (g.H - 1)) * g.os + g.py;
+                    const int ox = (m & (g.W - 1)) * g.os + g.px;
+                    o = (((long long)n * Ho + oy) * Wo + ox) * p.Cb + co;
+                    ro = p.res_ups ? (((long long)n * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * p.Cb + co : o;
                 }
+                float v = acc[i][j][e] * scale + bv;
+                if (p.res && first) v += p.res[ro];
                 if (p.mask_x) v *= (p.mask_x[o] > 0.f ? 1.0f : p.mask_slope);
                 if (p.ksplit > 1) atomicAdd(&p.y[o], v);
                 else p.y[o] = v;
@@ -700,6 +719,7 @@ static const bool g_force_kb16 = getenv("GIM_CONV_KB32") == nullptr;
 // Layers whose output tiles do not fill the chip (8x8 and smaller maps, the decoder head, linears) are sliced
 // along K over grid.z.  Measured sweep on MI355X (profiles/r01_ksplit_sweep.txt): best when the launch has about
 // two workgroups per CU (~512); beyond 6 slices the float atomics of the combine cost more than they buy.
+static const bool g_xcd = getenv("GIM_CONV_NO_XCD") == nullptr;  // A/B switch
 static const int g_force_ksplit = getenv("GIM_CONV_KSPLIT") ? atoi(getenv("GIM_CONV_KSPLIT")) : 0;  // experiments
 
 static int plan_ksplit(long long wgs, int nk) {
@@ -720,7 +740,10 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
     p.kper = (nk + p.ksplit - 1) / p.ksplit;
     p.ksplit = (nk + p.kper - 1) / p.kper;
     if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB>), dim3(gx, gy, p.ksplit * ncls), dim3(256), 0, st, p);
+    p.gx = gx; p.gy = gy;
+    p.xcd = (g_xcd && (long long)gx * gy >= 64) ? 1 : 0;
+    const dim3 grid = p.xcd ? dim3(((gx + 7) / 8) * 8 * gy, 1, p.ksplit * ncls) : dim3(gx, gy, p.ksplit * ncls);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB>), grid, dim3(256), 0, st, p);
 }
 
 template <int BM, int BN, int TM, int TN, int BMODE, int GEN>
