@@ -440,6 +440,7 @@ struct WgP {
     int mper;
     float pre_slope;   // leaky-relu on the gathered x operand
     float a_slope;     // leaky-relu on the dy operand (role-swapped use: sub-pixel conv wgrad)
+    int atomic;        // 1: all pixel slices add into ONE pre-zeroed slab with float atomics (no reduce pass)
 };
 
 // VEC = 4: dY rows and gathered x rows are fetched as float4 (Cout % 4 == 0, Cin % 4 == 0, 16-byte aligned
@@ -594,7 +595,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         __syncthreads();
     }
 
-    float* out = p.slabs + (long long)blockIdx.z * p.Cout * p.Kcols;
+    // each accumulator register is two 128-byte row segments per wave: the shape float atomics run at full rate for
+    float* out = p.slabs + (p.atomic ? 0 : (long long)blockIdx.z * p.Cout * p.Kcols);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -604,7 +606,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (co < p.Cout) out[(long long)co * p.Kcols + col] = acc[i][jj][e];
+                if (co < p.Cout) {
+                    if (p.atomic) atomicAdd(&out[(long long)co * p.Kcols + col], acc[i][jj][e]);
+                    else out[(long long)co * p.Kcols + col] = acc[i][jj][e];
+                }
             }
         }
 
@@ -616,7 +621,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         if (t < BM && co0 + t < p.Cout) {
             float sacc = 0.f;
             for (int rr = 0; rr < 256 / AU; ++rr) sacc += red[rr * BM + t];
-            p.bias_slabs[(long long)blockIdx.z * p.Cout + co0 + t] = sacc;
+            if (p.atomic) atomicAdd(&p.bias_slabs[co0 + t], sacc);
+            else p.bias_slabs[(long long)blockIdx.z * p.Cout + co0 + t] = sacc;
         }
     }
 }
@@ -847,9 +853,14 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     return q;
 }
 
+// Default: the pixel slices of one weight gradient are combined with float atomics in the kernel epilogue (the
+// caller sees ONE slab; no separate reduce pass - at 16 episodes per GPU that pass cost 7 % of the step).  The sum
+// order then varies from run to run in the last bits.  GIM_WGRAD_SLABS=1 restores the deterministic slab form.
+static const bool g_wgrad_atomic = getenv("GIM_WGRAD_SLABS") == nullptr;
+
 extern "C" int gim_conv2d_wgrad_slabs(const gim_conv_shape* s) {
     if (check_shape(s)) return GIM_E_BADARG;
-    return wgrad_plan(s).ns;
+    return g_wgrad_atomic ? 1 : wgrad_plan(s).ns;
 }
 
 template <int VEC>
@@ -867,7 +878,8 @@ extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, f
     if (rc) return rc;
     GIM_CHECK_ARG(dy && x && slabs, "conv wgrad: null pointer");
     const WgPlan q = wgrad_plan(s);
-    GIM_CHECK_ARG(n_slabs == q.ns, "conv wgrad: n_slabs must equal gim_conv2d_wgrad_slabs(shape)");
+    const bool atomic = g_wgrad_atomic && q.ns > 1;
+    GIM_CHECK_ARG(n_slabs == (g_wgrad_atomic ? 1 : q.ns), "conv wgrad: n_slabs must equal gim_conv2d_wgrad_slabs(shape)");
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(up_fold && bias_slabs), "conv wgrad: the sub-pixel form does not produce the bias gradient (use gim_colsum)");
     WgP p{};
@@ -880,7 +892,11 @@ extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, f
         p.dy = dy; p.x = x; p.Cin = s->Cin; p.Cout = s->Cout; p.pre_slope = s->pre_slope; p.a_slope = 1.f;
     }
     p.slabs = slabs; p.bias_slabs = bias_slabs;
-    p.M = q.M; p.Kcols = q.cols; p.mper = q.mper;
+    p.M = q.M; p.Kcols = q.cols; p.mper = q.mper; p.atomic = atomic ? 1 : 0;
+    if (atomic) {
+        (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
+        if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
+    }
     dim3 g((q.cols + q.bn - 1) / q.bn, (q.rows + q.bm - 1) / q.bm, q.ns);
     const bool vec = (s->Cin % 4 == 0) && (s->Cout % 4 == 0) && !(((uintptr_t)dy | (uintptr_t)x) & 15);
     if (vec) launch_wgrad<4>(p, q.bm, q.bn, g, (hipStream_t)stream);
