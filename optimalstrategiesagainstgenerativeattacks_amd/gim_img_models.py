@@ -7,6 +7,7 @@ NHWC.  ``GIMFaceImpersonator.forward`` takes one extra optional argument ``z`` s
 (drawn inside forward by the reference, gim_img_models.py:374) can be injected for parity tests.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -186,6 +187,17 @@ class GIMFaceDis(nn.Module):
         return self.mlp(x)
 
 
+_TWO_STREAMS = os.environ.get("GIM_SINGLE_STREAM") is None  # A/B switch
+_STREAMS = {}
+
+
+def _side_streams(device):
+    key = (device.type, device.index)
+    if key not in _STREAMS:
+        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _STREAMS[key]
+
+
 def _encode_sample(encoder, sample):
     """[B, t, C, S, S] (NCHW) -> [B, t, style_dim]."""
     B, t = sample.size(0), sample.size(1)
@@ -211,11 +223,33 @@ class GIMFaceAuthenticator(nn.Module):
 
     def forward(self, test_sample, si_sample):
         self.prefetch_spectral(2)
-        test_src = self.src_encode_sample(test_sample)
-        si_src = self.src_encode_sample(si_sample)
-        test_env = self.env_encode_sample(test_sample)
-        si_env = self.env_encode_sample(si_sample)
+        (test_src, si_src), (test_env, si_env) = self.encode_samples([test_sample, si_sample])
         return self.dis(test_src=test_src, test_env=test_env, si_src=si_src, si_env=si_env)
+
+    def encode_samples(self, samples):
+        """src- and env-encode every sample set.  The two encoders are independent networks: they run on two HIP
+        streams so that the small layers of one (8x8 and smaller maps, too few workgroups to fill 256 CUs at 16
+        episodes per GPU) overlap with the other's.  Per encoder the call order - hence the spectral-norm power
+        iteration order - is the reference's (each encoder sees the samples in list order on its own stream).
+        autograd replays each backward op on its forward stream, so the backward overlaps the same way."""
+        cur = torch.cuda.current_stream()
+        if not _TWO_STREAMS or not samples[0].is_cuda:
+            return ([self.src_encode_sample(s) for s in samples], [self.env_encode_sample(s) for s in samples])
+        streams = _side_streams(samples[0].device)
+        outs = []
+        for st, enc in zip(streams, (self.src_encoder, self.env_encoder)):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                feats = [_encode_sample(enc, s) for s in samples]
+            for f in feats:
+                f.record_stream(cur)  # produced on the side stream, consumed by the head on the current stream
+            outs.append(feats)
+        for s in samples:
+            for st in streams:
+                s.record_stream(st)
+        for st in streams:
+            cur.wait_stream(st)
+        return outs[0], outs[1]
 
     def src_encode_sample(self, sample):
         return _encode_sample(self.src_encoder, sample)

@@ -94,12 +94,9 @@ class GIMImgTrainer(nn.Module):
             raise NotImplementedError("reg_param > 0 (R1 double backward) is not on the accelerated path yet; use reg_param=0")
 
         self.authenticator.prefetch_spectral(3)  # si, real, fake: three calls of each encoder
-        au_si_src = self.authenticator.src_encode_sample(si_sample)
-        au_si_env = self.authenticator.env_encode_sample(si_sample)
-        au_real_src = self.authenticator.src_encode_sample(real_sample)
-        au_real_env = self.authenticator.env_encode_sample(real_sample)
-        au_fake_src = self.authenticator.src_encode_sample(fake_sample)
-        au_fake_env = self.authenticator.env_encode_sample(fake_sample)
+        # same per-encoder call order as the reference (si, real, fake); the two encoders run on two streams
+        (au_si_src, au_real_src, au_fake_src), (au_si_env, au_real_env, au_fake_env) = \
+            self.authenticator.encode_samples([si_sample, real_sample, fake_sample])
 
         out_on_real = self.authenticator.dis(test_src=au_real_src, test_env=au_real_env, si_src=au_si_src, si_env=au_si_env)
         loss_on_real = self.gan_loss(dis_out=out_on_real, target=1.)
