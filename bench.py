@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="episodes per GPU (default: 16 for vox64, 32 for om32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,10 +173,17 @@ def main():
     leaked, real, si = synthetic_batch(B, m, n, k, u["C"], u["S"], device, 1234 + rank)
     zgen = torch.Generator(device=device).manual_seed(4321 + rank)
 
+    graphed = None
+    if args.graph:
+        from optimalstrategiesagainstgenerativeattacks_amd.graph import GraphedGimStep
+        graphed = GraphedGimStep(trainer, leaked, real, si, torch.randn((B, n, 512), device=device, generator=zgen))
+
     def step():
         z = torch.randn((B, n, 512), device=device, generator=zgen)
         tr.do_global_step()
         tr.update_learning_rate()
+        if graphed is not None:
+            return graphed(leaked, real, si, z)
         return G.gim_step(trainer, leaked, real, si, z=z)
 
     def fence():
@@ -219,7 +227,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d synthetic episodes, m=%d n=%d k=%d, %d episodes/GPU, style_dim=512, "
                                    "G step + D step + 2 Adam updates per step, reg_param=0" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B),
-                       "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world},
+                       "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world,
+                       "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": measured_hbm_traffic(args.workload, B) if world == 1 else None, "traffic_unit": "HBM bytes/step (rocprofv3 PMC, profiles/)",

@@ -1,0 +1,52 @@
+"""hipGraph capture of one whole GIM training iteration (generator step + discriminator step + both Adam updates).
+
+The eager step issues ~2000 kernel launches through Python (~35-60 ms of host time per step): fine while the GPU
+needs longer than that (16 episodes per GPU), the bound once batches are small or kernels get faster.  A captured
+step replays with one launch.  Everything the step touches is capture-safe by construction: the C ABI allocates
+nothing and syncs nothing, Adam's step counter and learning rates live in device memory, the spectral-norm job
+tables are static, the two encoder streams fork from / join into the capturing stream.
+"""
+import torch
+
+from .gim_img_training import gim_step
+
+
+class GraphedGimStep:
+    """Usage:
+        gs = GraphedGimStep(trainer, leaked, real, si, z)     # shapes are frozen; runs warm-up steps, then captures
+        im_out, au_out = gs(leaked, real, si, z)               # copies into the static inputs and replays
+    The learning rates may change between replays (they are read from device memory; pushed before each replay).
+    Outputs are static tensors overwritten by the next replay.  Parameters, Adam state, spectral-norm buffers are
+    updated in place exactly as by the eager ``gim_step``; the host-side step counters are advanced here."""
+
+    def __init__(self, trainer, leaked, real, si, z, warmup=2):
+        self.trainer = trainer
+        self.mod = trainer.module
+        self.static = [t.clone() for t in (leaked, real, si, z)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                gim_step(trainer, *self.static[:3], z=self.static[3])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):
+            opt._push_lrs()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = gim_step(trainer, *self.static[:3], z=self.static[3])
+        # the capture pass itself advanced the host-side counters once without running: undo nothing, but note
+        # that parameters were NOT changed by the capture (kernels are only recorded)
+        for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):
+            opt.note_steps(-1)
+
+    def __call__(self, leaked, real, si, z):
+        for dst, src in zip(self.static, (leaked, real, si, z)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):
+            opt._push_lrs()
+        self.graph.replay()
+        for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):
+            opt.note_steps(1)
+        return self.out

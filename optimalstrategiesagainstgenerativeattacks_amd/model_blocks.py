@@ -114,10 +114,10 @@ class SNConv2d(nn.Module):
 
     def folded(self):
         """The (k+1)^2-tap folded weights for the pool / sub-pixel forms, recomputed only when weight_orig changed
-        (autograd version counter for torch-side writes, optim.weights_epoch() for the fused Adam kernel)."""
+        (autograd version counter for torch-side writes, optim.weights_epoch(w) for the fused Adam kernel)."""
         from . import optim
         w = self.weight_orig
-        key = (w.data_ptr(), w._version, optim.weights_epoch())
+        key = (w.data_ptr(), w._version, optim.weights_epoch(w))
         if self._fold_cache[0] != key:
             with torch.no_grad():
                 f = ops._folded(ops.weight_phys(w), self.out_channels, self.in_channels, self.kernel_size)

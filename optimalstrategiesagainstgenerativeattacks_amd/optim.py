@@ -35,13 +35,11 @@ def _view_like(flat_slice, ref):
     return flat_slice.view(ref.shape)
 
 
-_WEIGHTS_EPOCH = 0
-
-
-def weights_epoch():
-    """Bumped by every FusedAdam.step(): the Adam kernel writes parameters through raw pointers, which torch's
-    version counters do not see; caches derived from weights (folded conv weights) key on this."""
-    return _WEIGHTS_EPOCH
+def weights_epoch(p):
+    """Number of FusedAdam updates applied to parameter ``p``.  The Adam kernel writes parameters through raw
+    pointers, which torch's version counters do not see; caches derived from a weight (folded conv weights) key on
+    (p._version, weights_epoch(p))."""
+    return getattr(p, "_gim_epoch", 0)
 
 
 def _pad(n, align=64):
@@ -175,9 +173,14 @@ class FusedAdam(torch.optim.Optimizer):
                                 self.flat_p.numel(), self._seg_end.data_ptr(), self._lr_dev.data_ptr(), len(self.param_groups),
                                 g0["betas"][0], g0["betas"][1], g0["eps"], scale, self._step_dev.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream), "adam_step")
-        self._host_step += 1
-        global _WEIGHTS_EPOCH
-        _WEIGHTS_EPOCH += 1
+        self.note_steps(1)
+
+    def note_steps(self, k):
+        """Host-side bookkeeping of k applied updates (called by step(); call it yourself after replaying a captured
+        hipGraph that contains step(), since the replay does not run this Python code)."""
+        self._host_step += k
+        for p in self._offsets:
+            p._gim_epoch = getattr(p, "_gim_epoch", 0) + k
 
     # ------------------------------------------------------------------ checkpoint format
     def state_dict(self):

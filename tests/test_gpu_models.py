@@ -226,3 +226,45 @@ def test_product_vs_oracle_fp32_step_and_state():
         for kk, b in mod.named_buffers():
             assert relerr(b, sd_o[kk]) < 1e-3, (name, kk)
     assert len(bad) <= 3, bad[:10]
+
+
+def test_graphed_step_equals_eager_step():
+    """A step replayed from the captured hipGraph (graph.GraphedGimStep) updates parameters, Adam state and
+    spectral-norm buffers exactly like the eager gim_step (up to the order of float atomics)."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    from optimalstrategiesagainstgenerativeattacks_amd.graph import GraphedGimStep
+    import tempfile
+    tag, cfg = "graph", "16_1_32"
+    B, m, n, k, c, s, d = 2, 1, 3, 4, 1, 16, 32
+    runs = []
+    for graphed in (False, True):
+        au, im = _product_models(tag, cfg)
+        with tempfile.TemporaryDirectory() as td:
+            tr = G.GIMImgTrainer(td, m, n, k, au, im, 1e-3, 1e-3, 1e-4, reg_param=0.0)
+        trainer = G.DataParallelMock(tr)
+        eps = [[t.float().to(dev()) for t in episode("%s/%d" % (tag, it), B, m, n, k, c, s, d)] for it in range(3)]
+        outs = []
+        if graphed:
+            # capture on the first episode's shapes (warm-up steps run on scratch copies of the state)
+            state = ({k_: v.clone() for k_, v in au.state_dict().items()}, {k_: v.clone() for k_, v in im.state_dict().items()})
+            gs = GraphedGimStep(trainer, *eps[0], warmup=1)
+            au.load_state_dict(state[0]); im.load_state_dict(state[1])
+            for opt in (tr.authenticator_opt, tr.impersonator_opt):
+                opt.flat_m.zero_(); opt.flat_v.zero_(); opt._step_dev.zero_(); opt._host_step = 0
+            for leaked, real, si, z in eps:
+                gi, di = gs(leaked, real, si, z)
+                outs.append((gi[0].clone(), gi[2].clone(), di[0].clone()))
+        else:
+            for leaked, real, si, z in eps:
+                gi, di = G.gim_step(trainer, leaked, real, si, z=z)
+                outs.append((gi[0].clone(), gi[2].clone(), di[0].clone()))
+        runs.append((outs, {k_: v.clone() for k_, v in au.state_dict().items()}, tr.authenticator_opt._host_step))
+    (o_e, sd_e, st_e), (o_g, sd_g, st_g) = runs
+    assert st_e == st_g == 3
+    for it in range(3):
+        for a, b in zip(o_e[it], o_g[it]):
+            # after the first update the two runs differ by the order of the float atomics (Adam with beta1 = 0
+            # turns last-bit gradient differences into lr-sized weight differences); logits here are ~1e-3
+            assert relerr(b, a, atol=1e-3) < (1e-4 if it == 0 else 2e-2), it
+    worst = max(relerr(sd_g[k_], sd_e[k_]) for k_ in sd_e)
+    assert worst < 5e-3, worst
