@@ -17,6 +17,17 @@ from . import ops
 from .gim_basic_models import GIMMeanStdFcStat
 
 
+_TWO_STREAMS = os.environ.get("GIM_SINGLE_STREAM") is None  # A/B switch
+_STREAMS = {}
+
+
+def _side_streams(device):
+    key = (device.type, device.index)
+    if key not in _STREAMS:
+        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _STREAMS[key]
+
+
 class Encoder(nn.Module):
     """models/gim_img_models.py:19-57.  forward: NHWC [N, S, S, C] -> [N, style_dim]."""
 
@@ -109,9 +120,9 @@ class Img2ImgAdaInResModule(nn.Module):
         for _ in range(self.n_blocks):
             self.res_blocks.append(mb.AdaResBlock2(channels=style_dim, style_dim=style_dim))
 
-    def forward(self, x, style):
+    def forward(self, x, style, svs=None):
         for i in range(self.n_blocks):
-            x = self.res_blocks[i](x=x, style=style)
+            x = self.res_blocks[i](x=x, style=style, sv=None if svs is None else svs[i])
         return x
 
 
@@ -137,11 +148,11 @@ class Img2ImgAdaInUpModule(nn.Module):
                                                         style_dim=style_dim))
         self.att = mb.SelfAttention(self.channel_sizes[self.att_loc])
 
-    def forward(self, x, style):
+    def forward(self, x, style, svs=None):
         for i in range(self.n_up_blocks):
             if i == self.att_loc:
                 x = self.att(x)
-            x = self.up_blocks[i](x=x, style=style)
+            x = self.up_blocks[i](x=x, style=style, sv=None if svs is None else svs[i])
         return ops.tanh(x)
 
 
@@ -159,9 +170,25 @@ class AdaInImage2Image(nn.Module):
                                                    min_n_channels=min_n_channels)
 
     def forward(self, x, style):
+        # the 36 style linears (tiny, latency-bound GEMMs) depend on `style` only: run them all now on a side stream,
+        # under the down path, instead of in front of each AdaIN (autograd overlaps their backward the same way)
+        svs_res = svs_up = None
+        if _TWO_STREAMS and x.is_cuda:
+            cur = torch.cuda.current_stream()
+            side = _side_streams(x.device)[0]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                svs_res = [b.style_vectors(style) for b in self.adain_res_block.res_blocks]
+                svs_up = [b.style_vectors(style) for b in self.adain_up_block.up_blocks]
+            style.record_stream(side)
         x = self.down_block(x)
-        x = self.adain_res_block(x=x, style=style)
-        return self.adain_up_block(x=x, style=style)
+        if svs_res is not None:
+            cur.wait_stream(side)
+            for sv in svs_res + svs_up:
+                for t in sv:
+                    t.record_stream(cur)
+        x = self.adain_res_block(x=x, style=style, svs=svs_res)
+        return self.adain_up_block(x=x, style=style, svs=svs_up)
 
 
 class GIMFaceDis(nn.Module):
@@ -185,17 +212,6 @@ class GIMFaceDis(nn.Module):
         fc_si = self.stat.fc.per_sample(si_env)
         x = ops.head_cat(test_src, test_env, si_src, si_env, fc_test, fc_si)
         return self.mlp(x)
-
-
-_TWO_STREAMS = os.environ.get("GIM_SINGLE_STREAM") is None  # A/B switch
-_STREAMS = {}
-
-
-def _side_streams(device):
-    key = (device.type, device.index)
-    if key not in _STREAMS:
-        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-    return _STREAMS[key]
 
 
 def _encode_sample(encoder, sample):

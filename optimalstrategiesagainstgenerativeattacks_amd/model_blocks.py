@@ -333,9 +333,13 @@ class AdaResBlock2(nn.Module):
         self.conv1 = SNConv2d(channels, channels, 3, padding=1)
         self.conv2 = SNConv2d(channels, channels, 3, padding=1)
 
-    def forward(self, x, style):
-        m1, s1 = self.lin1_mean(style), self.lin1_std(style)
-        m2, s2 = self.lin2_mean(style), self.lin2_std(style)
+    def style_vectors(self, style):
+        """(mean1, std1, mean2, std2) of the two AdaINs: they depend on `style` only, so the image-to-image module
+        computes them for all its blocks up front on a side stream (Img2Img modules in gim_img_models.py)."""
+        return (self.lin1_mean(style), self.lin1_std(style), self.lin2_mean(style), self.lin2_std(style))
+
+    def forward(self, x, style, sv=None):
+        m1, s1, m2, s2 = sv if sv is not None else self.style_vectors(style)
         out = self.conv1(x)
         out = ops.ada_in(out, m1, s1)
         out = self.conv2(out, pre_slope=LRELU)
@@ -357,9 +361,11 @@ class AdaResBlockUp2(nn.Module):
         self.conv_r1 = SNConv2d(in_channels, out_channels, conv_size, padding=padding_size)
         self.conv_r2 = SNConv2d(out_channels, out_channels, conv_size, padding=padding_size)
 
-    def forward(self, x, style):
-        m1, s1 = self.lin1_mean(style), self.lin1_std(style)
-        m2, s2 = self.lin2_mean(style), self.lin2_std(style)
+    def style_vectors(self, style):
+        return (self.lin1_mean(style), self.lin1_std(style), self.lin2_mean(style), self.lin2_std(style))
+
+    def forward(self, x, style, sv=None):
+        m1, s1, m2, s2 = sv if sv is not None else self.style_vectors(style)
         left = self.conv_l1(x)
         out = ops.ada_in(x, m1, s1)
         out = self.conv_r1(out, ups=1, pre_slope=LRELU)
