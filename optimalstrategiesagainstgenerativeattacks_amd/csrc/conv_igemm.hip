@@ -726,6 +726,9 @@ static const bool g_force_kb16 = getenv("GIM_CONV_KB32") == nullptr;
 // along K over grid.z.  Measured sweep on MI355X (profiles/r01_ksplit_sweep.txt): best when the launch has about
 // two workgroups per CU (~512); beyond 6 slices the float atomics of the combine cost more than they buy.
 static const bool g_xcd = getenv("GIM_CONV_NO_XCD") == nullptr;  // A/B switch
+// below this many 128x128 output tiles a launch uses 64x64 tiles: 4x the workgroups and a 4x shorter MFMA chain per
+// K step (a workgroup cannot finish faster than its serial K loop: 0.85 us per step at 128x128)
+static const int g_small_tiles = getenv("GIM_CONV_SMALL_TILES") ? atoi(getenv("GIM_CONV_SMALL_TILES")) : 24;
 static const int g_force_ksplit = getenv("GIM_CONV_KSPLIT") ? atoi(getenv("GIM_CONV_KSPLIT")) : 0;  // experiments
 
 static int plan_ksplit(long long wgs, int nk) {
@@ -767,8 +770,12 @@ template <int BMODE, int GEN>
 static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K
     const int M = p.M, Cb = p.Cb;
+    static const int force_tile = getenv("GIM_CONV_TILE") ? atoi(getenv("GIM_CONV_TILE")) : 0;  // experiments
     if (Cb > 64) {
+        const long long t128 = (long long)((M + 127) / 128) * ((Cb + 127) / 128) * (p.g.pc ? 4 : 1);
+        const bool small = force_tile ? force_tile == 64 : t128 < g_small_tiles;
         if (M <= 64) launch_cfg<64, 128, 1, 2, BMODE, GEN>(p, y_elems, st);
+        else if (small) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
         else launch_cfg<128, 128, 2, 2, BMODE, GEN>(p, y_elems, st);
     } else if (Cb > 32) {
         if (M <= 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
