@@ -8,6 +8,7 @@ There is no CPU compute path: forward/backward/step need an MI355X and the built
 """
 from .gim_img_models import (AdaInImage2Image, Encoder, EnvDecoder, GIMFaceAuthenticator, GIMFaceDis,
                              GIMFaceImpersonator, get_au, get_im)
+from .gim_gaussian_trainer import GIMGaussianTrainer
 from .gim_img_trainer import GIMImgTrainer
 from .gim_img_training import au_eval_step, au_train_step, gim_step, im_eval_step, im_train_step
 from .optim import FusedAdam
@@ -15,6 +16,6 @@ from .training_utils import CheckpointIO, DataParallelMock, EpisodeParallel, Glo
 
 __all__ = [
     "get_au", "get_im", "Encoder", "EnvDecoder", "AdaInImage2Image", "GIMFaceDis", "GIMFaceAuthenticator",
-    "GIMFaceImpersonator", "GIMImgTrainer", "im_train_step", "au_train_step", "im_eval_step", "au_eval_step",
+    "GIMFaceImpersonator", "GIMImgTrainer", "GIMGaussianTrainer", "im_train_step", "au_train_step", "im_eval_step", "au_eval_step",
     "gim_step", "FusedAdam", "DataParallelMock", "EpisodeParallel", "GlobalStep", "CheckpointIO", "adjust_batch_size",
 ]

@@ -650,3 +650,43 @@ bce_logits = BCELogitsFn.apply
 
 def repeat_dim1(x, t):
     return RepeatDim1Fn.apply(x, t)
+
+
+class MeanStdCatFn(Function):
+    """cat([mean(x_i, 1), custom_std(x_i)] for each x_i [B, t_i, D]) -> [B, 2*D*len(xs)]
+    (GIMMeanStdStat of both sample sets + torch.cat, models/gim_gaussian_models.py:37-39)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        lib = _lib.load()
+        xs = [_req(x, "x") for x in xs]
+        B, _, D = xs[0].shape
+        L = 2 * D * len(xs)
+        out = torch.empty((B, L), device=xs[0].device, dtype=torch.float32)
+        st = _stream()
+        for i, x in enumerate(xs):
+            check(lib.gim_set_stats_fwd(_p(x), _p(out, 2 * D * i), _p(out, 2 * D * i + D), B, x.shape[1], D, L, L, st), "set_stats_fwd")
+        ctx.save_for_backward(*xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        xs = ctx.saved_tensors
+        dout = _req(dout, "dout")
+        B, _, D = xs[0].shape
+        L = dout.shape[1]
+        st = _stream()
+        grads = []
+        for i, x in enumerate(xs):
+            if not ctx.needs_input_grad[i]:
+                grads.append(None)
+                continue
+            dx = torch.empty_like(x)
+            check(lib.gim_set_stats_bwd(_p(x), _p(dout, 2 * D * i), _p(dout, 2 * D * i + D), _p(dx), B, x.shape[1], D, L, L, st), "set_stats_bwd")
+            grads.append(dx)
+        return tuple(grads)
+
+
+def mean_std_cat(*xs):
+    return MeanStdCatFn.apply(*xs)

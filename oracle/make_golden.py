@@ -297,9 +297,52 @@ def gen_trainer(tag, reg_param, n_steps=3, n_au_steps=1):
     print("trainer_%s: done" % tag)
 
 
+def gen_gaussian():
+    """BASELINE config 1: the Gaussian toy game (d=10, m=1, n=5, k=10), 5 consecutive iterations of the reference's
+    own im_train_step / au_train_step on fixed batches, fp64."""
+    import models.gim_gaussian_models as ggm
+    from training.gim_gaussian_trainer import GIMGaussianTrainer
+    import training.gim_gaussian_training as ggt
+    d, B, m, n, k = 10, 64, 1, 5, 10
+    torch.set_default_dtype(torch.float64)
+    st, keys = {}, {}
+    for tag, reg in (("gauss", 0.0), ("gauss_r1", 1.0)):
+        au = fill_module(ggm.get_au(d), tag + "/au/")
+        im = fill_module(ggm.get_im(d), tag + "/im/")
+        keys = {"au": key_list(au), "im": key_list(im), "au_params": param_names(au), "im_params": param_names(im)}
+        with tempfile.TemporaryDirectory() as td:
+            tr = GIMGaussianTrainer(td, m, n, k, au, im, au_lr=1e-3, im_lr=2e-3, reg_param=reg)
+        trainer = DataParallelMock(tr)
+        for it in range(5):
+            mu = pf.normal("%s/it%d/mu" % (tag, it), (B, 1, d))
+            smp = lambda nm, t: T(mu + 0.7 * pf.normal("%s/it%d/%s" % (tag, it, nm), (B, t, d)))  # noqa: E731
+            leaked, real, si = smp("leaked", m), smp("real", n), smp("si", k)
+            z = T(pf.normal("%s/it%d/z" % (tag, it), (B, n, d)))
+            tr.do_global_step()
+            with inject_randn(z):
+                g = ggt.im_train_step(trainer, leaked, si)
+            dres = ggt.au_train_step(trainer, real, g[1], si)
+            st["%s/it%d/g_loss" % (tag, it)] = g[0].numpy()
+            st["%s/it%d/fake" % (tag, it)] = g[1].numpy()
+            st["%s/it%d/g_out" % (tag, it)] = g[2].numpy()
+            for i, nm in enumerate(["loss", "loss_real", "loss_fake", "reg", "out_real", "out_fake"]):
+                st["%s/it%d/d_%s" % (tag, it, nm)] = np.asarray(dres[i].numpy())
+        for kk, v in au.state_dict().items():
+            st["%s/final/au/%s" % (tag, kk)] = v.numpy()
+        for kk, v in im.state_dict().items():
+            st["%s/final/im/%s" % (tag, kk)] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "gaussian.npz"), **st)
+    with open(os.path.join(OUT, "gaussian.json"), "w") as f:
+        json.dump({"config": dict(d=d, B=B, m=m, n=n, k=k, au_lr=1e-3, im_lr=2e-3, sigma=0.7), "keys": keys}, f)
+    torch.set_default_dtype(torch.float32)
+    print("gaussian: done")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "keys", "tiny", "trainer", "bench"]
+    which = sys.argv[1:] or ["blocks", "keys", "tiny", "trainer", "bench", "gaussian"]
+    if "gaussian" in which:
+        gen_gaussian()
     if "blocks" in which:
         gen_blocks()
     if "keys" in which:

@@ -204,3 +204,30 @@ def test_bench_shape_64_fp32_tolerance():
     """fp32 oracle vs the reference's own fp32 run at the 64x64x3 benchmark shape:
     within the 1e-3 tolerance north_star states for losses/logits."""
     _check_nets("vox64_f32", "64_3_512", torch.float32, 1e-3, 5e-2, floor_frac=1e-3)
+
+
+@pytest.mark.parametrize("tag,reg", [("gauss", 0.0), ("gauss_r1", 1.0)])
+def test_gaussian_toy_game_trainer(tag, reg):
+    """BASELINE config 1 (d=10, m=1, n=5, k=10): 5 iterations of the reference's Gaussian trainer, with and without R1."""
+    g = load_npz("gaussian.npz")
+    meta = load_json("gaussian.json")
+    c = meta["config"]
+    au = filled_sd(meta["keys"]["au"], tag + "/au/")
+    im = filled_sd(meta["keys"]["im"], tag + "/im/")
+    tr = go.OracleGaussianTrainer(au, im, c["n"], c["au_lr"], c["im_lr"], reg_param=reg)
+    for it in range(5):
+        mu = pf.normal("%s/it%d/mu" % (tag, it), (c["B"], 1, c["d"]))
+        smp = lambda nm, t: T(mu + c["sigma"] * pf.normal("%s/it%d/%s" % (tag, it, nm), (c["B"], t, c["d"])))  # noqa: E731
+        leaked, real, si = smp("leaked", c["m"]), smp("real", c["n"]), smp("si", c["k"])
+        z = T(pf.normal("%s/it%d/z" % (tag, it), (c["B"], c["n"], c["d"])))
+        g_loss, fake, out, d_loss, out_real, out_fake = tr.step(leaked, real, si, z)
+        assert relerr(g_loss.mean(), g["%s/it%d/g_loss" % (tag, it)]) < 1e-9
+        assert relerr(fake, g["%s/it%d/fake" % (tag, it)]) < 1e-9
+        assert relerr(out, g["%s/it%d/g_out" % (tag, it)]) < 1e-9
+        assert relerr(d_loss.mean(), g["%s/it%d/d_loss" % (tag, it)]) < 1e-9
+        assert relerr(out_real.mean(), g["%s/it%d/d_out_real" % (tag, it)]) < 1e-9
+    for kk in au:
+        assert relerr(au[kk], g["%s/final/au/%s" % (tag, kk)]) < 1e-9, kk
+    for kk in im:
+        if not kk.startswith("out_mlp"):
+            assert relerr(im[kk], g["%s/final/im/%s" % (tag, kk)]) < 1e-9, kk
