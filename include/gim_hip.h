@@ -189,6 +189,14 @@ int gim_noise_combine(const float* env, const float* w, float* y, int B, int t, 
 int gim_concat2(const float* a, const float* b, float* y, int64_t R, int Ca, int Cb, int P, int rep, void* stream);
 int gim_slice_channels(const float* dy, float* da, int64_t R, int Ca, int Cy, void* stream);
 
+/* ImgAttention mix (models/model_blocks.py:598-608; only with use_img_att): per pixel (P pixels, C channels, NHWC)
+ * s1 = sum_c q1*k1, s2 = sum_c q2*k2, (a1, a2) = softmax(s1, s2), out = x1*a1 + v2*a2; att [P] keeps a1. */
+int gim_img_att_mix_fwd(const float* q1, const float* k1, const float* q2, const float* k2, const float* x1, const float* v2,
+                        float* out, float* att, int64_t P, int C, void* stream);
+int gim_img_att_mix_bwd(const float* dout, const float* q1, const float* k1, const float* q2, const float* k2, const float* x1,
+                        const float* v2, const float* att, float* dq1, float* dk1, float* dq2, float* dk2, float* dx1, float* dv2,
+                        int64_t P, int C, void* stream);
+
 /* Fused multi-tensor Adam on flat buffers (torch.optim.Adam form, no weight decay;
  * training/gim_img_trainer.py:50-58).  seg_end[n_seg] are exclusive element offsets of the parameter
  * groups, lr[n_seg] their learning rates (device arrays).  `step` is a device int32 incremented by the call

@@ -57,6 +57,8 @@ SIGNATURES = {
     "gim_noise_combine": [P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_concat2": [P, P, P, c_int64, c_int, c_int, c_int, c_int, P],
     "gim_slice_channels": [P, P, c_int64, c_int, c_int, P],
+    "gim_img_att_mix_fwd": [P, P, P, P, P, P, P, P, c_int64, c_int, P],
+    "gim_img_att_mix_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, P],
     "gim_adam_step": [P, P, P, P, c_int64, P, P, c_int, c_float, c_float, c_float, c_float, P, P],
     "gim_version": [],
 }

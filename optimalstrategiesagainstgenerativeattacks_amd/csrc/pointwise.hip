@@ -477,3 +477,64 @@ extern "C" int gim_slice_channels(const float* dy, float* da, int64_t R, int Ca,
     hipLaunchKernelGGL(slice_channels_kernel, dim3(pw_blocks(R * Ca)), dim3(256), 0, (hipStream_t)stream, dy, da, (long long)R, Ca, Cy);
     return gim_check_launch("gim_slice_channels");
 }
+
+// ---------------------------------------------------------------- ImgAttention mix (models/model_blocks.py:598-608)
+// s1 = sum_c q1*k1, s2 = sum_c q2*k2, (a1, a2) = softmax(s1, s2); out = x1*a1 + v2*a2.   One thread per pixel.
+__global__ __launch_bounds__(256) void img_att_mix_fwd_kernel(const float* __restrict__ q1, const float* __restrict__ k1,
+                                                              const float* __restrict__ q2, const float* __restrict__ k2,
+                                                              const float* __restrict__ x1, const float* __restrict__ v2,
+                                                              float* __restrict__ out, float* __restrict__ att, long long P, int C) {
+    GRID_STRIDE(i, P) {
+        const long long o = i * C;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            s1 += q1[o + c] * k1[o + c];
+            s2 += q2[o + c] * k2[o + c];
+        }
+        const float a1 = 1.0f / (1.0f + expf(s2 - s1));
+        att[i] = a1;
+        for (int c = 0; c < C; ++c) out[o + c] = x1[o + c] * a1 + v2[o + c] * (1.0f - a1);
+    }
+}
+__global__ __launch_bounds__(256) void img_att_mix_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ q1,
+                                                              const float* __restrict__ k1, const float* __restrict__ q2,
+                                                              const float* __restrict__ k2, const float* __restrict__ x1,
+                                                              const float* __restrict__ v2, const float* __restrict__ att,
+                                                              float* __restrict__ dq1, float* __restrict__ dk1, float* __restrict__ dq2,
+                                                              float* __restrict__ dk2, float* __restrict__ dx1, float* __restrict__ dv2,
+                                                              long long P, int C) {
+    GRID_STRIDE(i, P) {
+        const long long o = i * C;
+        const float a1 = att[i], a2 = 1.0f - a1;
+        float da1 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float d = dout[o + c];
+            dx1[o + c] = d * a1;
+            dv2[o + c] = d * a2;
+            da1 += d * (x1[o + c] - v2[o + c]);
+        }
+        const float ds1 = da1 * a1 * a2;
+        for (int c = 0; c < C; ++c) {
+            dq1[o + c] = ds1 * k1[o + c];
+            dk1[o + c] = ds1 * q1[o + c];
+            dq2[o + c] = -ds1 * k2[o + c];
+            dk2[o + c] = -ds1 * q2[o + c];
+        }
+    }
+}
+extern "C" int gim_img_att_mix_fwd(const float* q1, const float* k1, const float* q2, const float* k2, const float* x1,
+                                   const float* v2, float* out, float* att, int64_t P, int C, void* stream) {
+    GIM_CHECK_ARG(q1 && k1 && q2 && k2 && x1 && v2 && out && att && P > 0 && C > 0, "img_att_mix_fwd: bad args");
+    hipLaunchKernelGGL(img_att_mix_fwd_kernel, dim3(pw_blocks(P)), dim3(256), 0, (hipStream_t)stream, q1, k1, q2, k2, x1, v2, out, att,
+                       (long long)P, C);
+    return gim_check_launch("gim_img_att_mix_fwd");
+}
+extern "C" int gim_img_att_mix_bwd(const float* dout, const float* q1, const float* k1, const float* q2, const float* k2,
+                                   const float* x1, const float* v2, const float* att, float* dq1, float* dk1, float* dq2, float* dk2,
+                                   float* dx1, float* dv2, int64_t P, int C, void* stream) {
+    GIM_CHECK_ARG(dout && q1 && k1 && q2 && k2 && x1 && v2 && att && dq1 && dk1 && dq2 && dk2 && dx1 && dv2 && P > 0 && C > 0,
+                  "img_att_mix_bwd: bad args");
+    hipLaunchKernelGGL(img_att_mix_bwd_kernel, dim3(pw_blocks(P)), dim3(256), 0, (hipStream_t)stream, dout, q1, k1, q2, k2, x1, v2, att,
+                       dq1, dk1, dq2, dk2, dx1, dv2, (long long)P, C);
+    return gim_check_launch("gim_img_att_mix_bwd");
+}

@@ -291,10 +291,9 @@ class GIMFaceImpersonator(nn.Module):
         self._sn_plan = None
 
     def forward(self, leaked_sample, n, remove_noise_mean=True, z=None):
-        if self.use_img_att:
-            raise NotImplementedError("use_img_att=True is not on the accelerated hot path yet")
         if self._sn_plan is None:
-            self._sn_plan = mb.SNPlan(mb.sn_convs(self.src_encoder, self.env_encoder, self.env_decoder, self.img2img))
+            mods = [self.src_encoder, self.env_encoder, self.env_decoder, self.img2img] + ([self.img_att] if self.use_img_att else [])
+            self._sn_plan = mb.SNPlan(mb.sn_convs(*mods))
         self._sn_plan.run(1, self.training)
         B, m, C, S, _ = leaked_sample.size()
         leaked = ops.to_nhwc(leaked_sample.reshape(B * m, C, S, S))
@@ -309,6 +308,9 @@ class GIMFaceImpersonator(nn.Module):
         x = ops.concat2(env_img, first, n)
         style = ops.repeat_dim1(src, n).view(B * n, self.style_dim)
         out = self.img2img(x=x, style=style)
+        if self.use_img_att:  # models/gim_img_models.py:391-396
+            x1 = ops.repeat_dim1(first.reshape(B, S * S * C), n).view(B * n, S, S, C)
+            out = self.img_att(x1=x1, x2=out)
         return ops.to_nchw(out).view(B, n, C, S, S)
 
     def src_encode_sample(self, sample):

@@ -281,9 +281,8 @@ class ImgAttConvBlock(nn.Module):
 
 
 class ImgAttention(nn.Module):
-    """models/model_blocks.py:581-608.  Parameters always exist (they are in the reference's state dict and
-    optimizer group); the forward is only reachable with use_img_att=True, which is outside the round-1
-    hot-path scope."""
+    """models/model_blocks.py:581-608: per-pixel 2-way attention between the leaked image x1 and the generated image
+    x2 (only reached with use_img_att=True; the parameters always exist).  NHWC in, NHWC out."""
 
     def __init__(self, img1_channels, img2_channels):
         super().__init__()
@@ -294,7 +293,10 @@ class ImgAttention(nn.Module):
         self.v2conv = ImgAttConvBlock(img2_channels, img1_channels)
 
     def forward(self, x1, x2):
-        raise NotImplementedError("use_img_att=True is not on the accelerated hot path yet")
+        x = ops.concat2(x1, x2, 1)
+        q1, q2 = self.q1conv(x), self.q2conv(x)
+        k1, k2, v2 = self.k1conv(x1), self.k2conv(x2), self.v2conv(x2)
+        return ops.img_att_mix(q1, k1, q2, k2, x1, v2)
 
 
 class ResBlockUp(nn.Module):

@@ -542,6 +542,7 @@ class Concat2Fn(Function):
         y = torch.empty((Ni, H, W, Ca + Cb), device=a.device, dtype=torch.float32)
         check(lib.gim_concat2(_p(a), _p(b), _p(y), Ni * H * W, Ca, Cb, H * W, rep, _stream()), "concat2")
         ctx.cfg = (Ni, H, W, Ca, Cb)
+        ctx.rep = rep
         return y
 
     @staticmethod
@@ -549,9 +550,16 @@ class Concat2Fn(Function):
         lib = _lib.load()
         Ni, H, W, Ca, Cb = ctx.cfg
         dy = _req(dy, "dy")
-        da = torch.empty((Ni, H, W, Ca), device=dy.device, dtype=torch.float32)
-        check(lib.gim_slice_channels(_p(dy), _p(da), Ni * H * W, Ca, Ca + Cb, _stream()), "slice_channels")
-        return da, None, None
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty((Ni, H, W, Ca), device=dy.device, dtype=torch.float32)
+            check(lib.gim_slice_channels(_p(dy), _p(da), Ni * H * W, Ca, Ca + Cb, _stream()), "slice_channels")
+        if ctx.needs_input_grad[1]:
+            if ctx.rep != 1:
+                raise RuntimeError("concat2: gradient w.r.t. a broadcast second operand is not implemented")
+            db = torch.empty((Ni, H, W, Cb), device=dy.device, dtype=torch.float32)
+            check(lib.gim_slice_channels(_p(dy, Ca), _p(db), Ni * H * W, Cb, Ca + Cb, _stream()), "slice_channels")
+        return da, db, None
 
 
 class HeadCatFn(Function):
@@ -690,3 +698,32 @@ class MeanStdCatFn(Function):
 
 def mean_std_cat(*xs):
     return MeanStdCatFn.apply(*xs)
+
+
+class ImgAttMixFn(Function):
+    """out = x1 * a1 + v2 * a2 with (a1, a2) = softmax(sum_c q1*k1, sum_c q2*k2)  (ImgAttention, NHWC)."""
+
+    @staticmethod
+    def forward(ctx, q1, k1, q2, k2, x1, v2):
+        lib = _lib.load()
+        ts = [_req(t, "img_att input") for t in (q1, k1, q2, k2, x1, v2)]
+        N, H, W, C = ts[0].shape
+        out = torch.empty_like(ts[0])
+        att = torch.empty((N, H, W), device=out.device, dtype=torch.float32)
+        check(lib.gim_img_att_mix_fwd(*[_p(t) for t in ts], _p(out), _p(att), N * H * W, C, _stream()), "img_att_mix_fwd")
+        ctx.save_for_backward(*ts, att)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q1, k1, q2, k2, x1, v2, att = ctx.saved_tensors
+        dout = _req(dout, "dout")
+        N, H, W, C = q1.shape
+        gs = [torch.empty_like(q1) for _ in range(6)]
+        check(lib.gim_img_att_mix_bwd(_p(dout), _p(q1), _p(k1), _p(q2), _p(k2), _p(x1), _p(v2), _p(att), *[_p(g) for g in gs],
+                                      N * H * W, C, _stream()), "img_att_mix_bwd")
+        return tuple(gs)
+
+
+img_att_mix = ImgAttMixFn.apply

@@ -129,6 +129,7 @@ def gen_blocks():
     run_block(st, "selfatt", mb.SelfAttention(16), {"x": (2, 16, 4, 4)}, lambda m, x: m(x))
     run_block(st, "selfatt_eval", mb.SelfAttention(16), {"x": (2, 16, 4, 4)}, lambda m, x: m(x), training=False)
     run_block(st, "mlp", mb.MLP((6, 10, 12, 4)), {"x": (5, 6)}, lambda m, x: m(x))
+    run_block(st, "imgatt", mb.ImgAttention(3, 3), {"x1": (2, 3, 16, 16), "x2": (2, 3, 16, 16)}, lambda m, x1, x2: m(x1, x2))
     stat = gbm.GIMMeanStdFcStat(style_dim=8, fc_n_stats=2, fc_hidden_layers=(16, 24, 16))
     run_block(st, "stat", stat, {"x": (3, 5, 8)}, lambda m, x: m(x))
     run_block(st, "stat_k1", gbm.GIMMeanStdFcStat(8, 2, (16, 24, 16)), {"x": (3, 1, 8)}, lambda m, x: m(x))
@@ -185,9 +186,9 @@ def gen_keys():
     print("state_dict_keys.json written")
 
 
-def make_models(s, c, d, tag, dtype):
+def make_models(s, c, d, tag, dtype, use_img_att=False):
     au = fill_module(gim.get_au(s, c, d), tag + "au/", dtype)
-    im = fill_module(gim.get_im(s, c, d), tag + "im/", dtype)
+    im = fill_module(gim.get_im(s, c, d, use_img_att=use_img_att), tag + "im/", dtype)
     return au, im
 
 
@@ -201,12 +202,12 @@ def grad_norms(mod):
     return {k: float(p.grad.double().norm()) for k, p in mod.named_parameters() if p.grad is not None}
 
 
-def gen_nets(tag, s, c, d, B, m, n, k, dtype, full):
+def gen_nets(tag, s, c, d, B, m, n, k, dtype, full, use_img_att=False):
     """Whole-net forward/backward of the two agents (impersonator_forward then
     authenticator_forward, no optimiser) with outputs and per-tensor grad norms."""
     torch.set_default_dtype(dtype)
     st, meta = {}, {}
-    au, im = make_models(s, c, d, tag + "/", dtype)
+    au, im = make_models(s, c, d, tag + "/", dtype, use_img_att)
     leaked, real, si, z = episode(tag, B, m, n, k, c, s, d, dtype)
     with tempfile.TemporaryDirectory() as td:
         tr = GIMImgTrainer(td, m, n, k, au, im, 1e-4, 1e-4, 1e-6, reg_param=0.0)
@@ -350,6 +351,7 @@ def main():
     if "tiny" in which:
         gen_nets("tiny64", 16, 1, 32, 2, 1, 3, 4, torch.float64, full=True)
         gen_nets("tiny_m2", 16, 1, 32, 2, 2, 2, 1, torch.float64, full=False)
+        gen_nets("tiny_att", 16, 1, 32, 2, 1, 3, 4, torch.float64, full=False, use_img_att=True)
     if "trainer" in which:
         gen_trainer("reg0", 0.0)
         gen_trainer("reg10", 10.0)

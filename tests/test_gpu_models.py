@@ -43,10 +43,11 @@ def _blocks():
         "adaresup9": (lambda: mb.AdaResBlockUp2(8, 3, 6, conv_size=9, padding_size=4), dict(x=(2, 8, 8, 8), style=(2, 6)), ("x", "style")),
         "selfatt": (lambda: mb.SelfAttention(16), dict(x=(2, 16, 4, 4)), ("x",)),
         "mlp": (lambda: mb.MLP((6, 10, 12, 4)), dict(x=(5, 6)), ("x",)),
+        "imgatt": (lambda: mb.ImgAttention(3, 3), dict(x1=(2, 3, 16, 16), x2=(2, 3, 16, 16)), ("x1", "x2")),
     }
 
 
-@pytest.mark.parametrize("name", ["resdown3", "resdown9", "resup", "resup1x1", "adares", "adaresup3", "adaresup9", "selfatt", "mlp"])
+@pytest.mark.parametrize("name", ["resdown3", "resdown9", "resup", "resup1x1", "adares", "adaresup3", "adaresup9", "selfatt", "mlp", "imgatt"])
 def test_block_vs_reference_golden(name):
     """Same named weights / inputs as oracle/make_golden.py fed to the reference block (fp64)."""
     g = load_npz("blocks.npz")
@@ -75,11 +76,11 @@ def test_block_vs_reference_golden(name):
             assert relerr(bufs[k[len(name) + 3:]], g[k]) < 1e-5, k
 
 
-def _product_models(tag, cfg):
+def _product_models(tag, cfg, use_img_att=False):
     import optimalstrategiesagainstgenerativeattacks_amd as G
     s, c, d = map(int, cfg.split("_"))
     keys = load_keys(cfg)
-    au, im = G.get_au(s, c, d), G.get_im(s, c, d)
+    au, im = G.get_au(s, c, d), G.get_im(s, c, d, use_img_att=use_img_att)
     au.load_state_dict(filled_sd(keys["au"], tag + "/au/", torch.float32))
     im.load_state_dict(filled_sd(keys["im"], tag + "/im/", torch.float32))
     return au.to(dev()), im.to(dev())
@@ -96,13 +97,13 @@ def _grad_norm_check(mod, ref, tol, floor_frac, what):
     assert not bad, "%s: %d/%d grad norms off, first: %s" % (what, len(bad), len(ref), bad[:5])
 
 
-def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3):
+def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3, use_img_att=False):
     import optimalstrategiesagainstgenerativeattacks_amd as G
     import tempfile
     g = load_npz("nets_%s.npz" % tag)
     meta = load_json("nets_%s.json" % tag)
     c = meta["config"]
-    au, im = _product_models(tag, cfg)
+    au, im = _product_models(tag, cfg, use_img_att)
     leaked, real, si, z = [t.float().to(dev()) for t in episode(tag, c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
     with tempfile.TemporaryDirectory() as td:
         tr = G.GIMImgTrainer(td, c["m"], c["n"], c["k"], au, im, 1e-4, 1e-4, 1e-6, reg_param=0.0)
@@ -138,6 +139,11 @@ def test_tiny_nets_vs_reference_golden():
 
 def test_tiny_nets_m2_vs_reference_golden():
     _check_nets("tiny_m2", "16_1_32", 1e-3, 2e-2)
+
+
+def test_tiny_nets_img_att_vs_reference_golden():
+    """use_img_att=True: the optional ImgAttention branch of the impersonator."""
+    _check_nets("tiny_att", "16_1_32", 1e-3, 2e-2, use_img_att=True)
 
 
 def test_omniglot_shape_vs_reference_golden():

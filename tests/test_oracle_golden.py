@@ -29,6 +29,7 @@ BLOCKS = {
     "selfatt": (dict(x=(2, 16, 4, 4)), lambda sd, x: go.self_attention(sd, "", x, True)),
     "selfatt_eval": (dict(x=(2, 16, 4, 4)), lambda sd, x: go.self_attention(sd, "", x, False)),
     "mlp": (dict(x=(5, 6)), lambda sd, x: go.mlp(sd, "", x)),
+    "imgatt": (dict(x1=(2, 3, 16, 16), x2=(2, 3, 16, 16)), lambda sd, x1, x2: go.img_attention(sd, "", x1, x2, True)),
     "stat": (dict(x=(3, 5, 8)), lambda sd, x: go.mean_std_fc_stat(sd, "", x)),
     "stat_k1": (dict(x=(3, 1, 8)), lambda sd, x: go.mean_std_fc_stat(sd, "", x)),
     "dis": (dict(test_src=(3, 5, 8), test_env=(3, 5, 8), si_src=(3, 4, 8), si_env=(3, 4, 8)),
@@ -102,13 +103,13 @@ def _check_grad_norms(sd, ref, gtol, floor_frac=1e-6):
         assert abs(float(sd[k].grad.norm()) - v) <= gtol * max(v, floor), k
 
 
-def _check_nets(tag, cfg, dtype, tol, gtol, floor_frac=1e-6):
+def _check_nets(tag, cfg, dtype, tol, gtol, floor_frac=1e-6, use_img_att=False):
     g = load_npz("nets_%s.npz" % tag)
     meta = load_json("nets_%s.json" % tag)
     c = meta["config"]
     au, im = _models(tag, cfg, dtype)
     leaked, real, si, z = episode(tag, c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"], dtype)
-    loss, fake, out = go.impersonator_forward(au, im, leaked, si, c["n"], z, True, True)
+    loss, fake, out = go.impersonator_forward(au, im, leaked, si, c["n"], z, True, True, use_img_att=use_img_att)
     assert relerr(loss, g["g/loss"]) < tol
     assert relerr(out, g["g/out"]) < tol
     gf = g["g/fake"]
@@ -141,6 +142,11 @@ def test_tiny_nets_fp64():
 
 def test_tiny_nets_m2_fp64():
     _check_nets("tiny_m2", "16_1_32", torch.float64, 1e-9, 1e-7)
+
+
+def test_tiny_nets_img_att_fp64():
+    """use_img_att=True (ImgAttention branch, models/gim_img_models.py:391-396)."""
+    _check_nets("tiny_att", "16_1_32", torch.float64, 1e-9, 1e-7, use_img_att=True)
 
 
 def test_trainer_protocol_reg0():
