@@ -189,6 +189,18 @@ int gim_noise_combine(const float* env, const float* w, float* y, int B, int t, 
 int gim_concat2(const float* a, const float* b, float* y, int64_t R, int Ca, int Cb, int P, int rep, void* stream);
 int gim_slice_channels(const float* dy, float* da, int64_t R, int Ca, int Cy, void* stream);
 
+/* Second-order pieces of the R1 regulariser (training/utils.py:115-124: autograd.grad(create_graph=True) of the
+ * authenticator output w.r.t. its input images, then backward through that gradient).  Convolutions need nothing
+ * new (the adjoint of dgrad is the forward conv, its weight derivative is wgrad); these are the other adjoints. */
+int gim_maxpool_gather(const float* gdx, const float* y, const int32_t* idx, float* gdy, int N, int HW, int C, float slope, void* stream);
+int gim_softmax_dim1_bwd_dp(const float* gs, const float* dp, const float* p, float* gp, int B, int R, int Ccols, void* stream);
+int gim_set_stats_bwd_bwd(const float* x, const float* dstd, const float* g, float* g_dmean, float* g_dstd, float* gx, int B, int t, int D,
+                          int64_t ld_dstd, int64_t ld_out, void* stream);
+int gim_lrelu_mask_mul(const float* g, const float* x, float slope, float* out, int64_t n, void* stream);
+/* out[b] = sum_i x[b][i]^2 over L elements per episode, and dx = 2 * x * dout[b]. */
+int gim_sqsum_rows_fwd(const float* x, float* out, int B, int64_t L, void* stream);
+int gim_sqsum_rows_bwd(const float* x, const float* dout, float* dx, int B, int64_t L, void* stream);
+
 /* ImgAttention mix (models/model_blocks.py:598-608; only with use_img_att): per pixel (P pixels, C channels, NHWC)
  * s1 = sum_c q1*k1, s2 = sum_c q2*k2, (a1, a2) = softmax(s1, s2), out = x1*a1 + v2*a2; att [P] keeps a1. */
 int gim_img_att_mix_fwd(const float* q1, const float* k1, const float* q2, const float* k2, const float* x1, const float* v2,

@@ -57,6 +57,12 @@ SIGNATURES = {
     "gim_noise_combine": [P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_concat2": [P, P, P, c_int64, c_int, c_int, c_int, c_int, P],
     "gim_slice_channels": [P, P, c_int64, c_int, c_int, P],
+    "gim_maxpool_gather": [P, P, P, P, c_int, c_int, c_int, c_float, P],
+    "gim_softmax_dim1_bwd_dp": [P, P, P, P, c_int, c_int, c_int, P],
+    "gim_set_stats_bwd_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int64, c_int64, P],
+    "gim_lrelu_mask_mul": [P, P, c_float, P, c_int64, P],
+    "gim_sqsum_rows_fwd": [P, P, c_int, c_int64, P],
+    "gim_sqsum_rows_bwd": [P, P, P, c_int, c_int64, P],
     "gim_img_att_mix_fwd": [P, P, P, P, P, P, P, P, c_int64, c_int, P],
     "gim_img_att_mix_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, P],
     "gim_adam_step": [P, P, P, P, c_int64, P, P, c_int, c_float, c_float, c_float, c_float, P, P],

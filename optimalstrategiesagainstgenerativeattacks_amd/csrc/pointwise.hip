@@ -538,3 +538,133 @@ extern "C" int gim_img_att_mix_bwd(const float* dout, const float* q1, const flo
                        dq1, dk1, dq2, dk2, dx1, dv2, (long long)P, C);
     return gim_check_launch("gim_img_att_mix_bwd");
 }
+
+// ---------------------------------------------------------------- second-order helpers (R1 regulariser)
+// adjoint of maxpool_lrelu_bwd: g_dy[n][c] = g_dx[n][idx[n][c]][c] * lrelu'(y[n][c])
+__global__ __launch_bounds__(256) void maxpool_gather_kernel(const float* __restrict__ gdx, const float* __restrict__ y,
+                                                             const int32_t* __restrict__ idx, float* __restrict__ gdy, int N, int HW, int C,
+                                                             float slope) {
+    const long long n_nc = (long long)N * C;
+    GRID_STRIDE(i, n_nc) {
+        const int c = (int)(i % C);
+        const long long n = i / C;
+        gdy[i] = gdx[(n * HW + idx[i]) * C + c] * (y[i] > 0.f ? 1.0f : slope);
+    }
+}
+extern "C" int gim_maxpool_gather(const float* gdx, const float* y, const int32_t* idx, float* gdy, int N, int HW, int C, float slope,
+                                  void* stream) {
+    GIM_CHECK_ARG(gdx && y && idx && gdy && N > 0 && HW > 0 && C > 0, "maxpool_gather: bad args");
+    hipLaunchKernelGGL(maxpool_gather_kernel, dim3(pw_blocks((long long)N * C)), dim3(256), 0, (hipStream_t)stream, gdx, y, idx, gdy, N, HW, C,
+                       slope);
+    return gim_check_launch("gim_maxpool_gather");
+}
+
+// derivative of the softmax backward  dS = P * (dP - c),  c_j = sum_i P_ij dP_ij  w.r.t. P, contracted with gS:
+//   gP_ij = gS_ij * (dP_ij - c_j) - dP_ij * d_j,   d_j = sum_i gS_ij P_ij        (columns j of [B][R][Cc])
+__global__ __launch_bounds__(256) void softmax_dim1_bwd_dp_kernel(const float* __restrict__ gs, const float* __restrict__ dp,
+                                                                  const float* __restrict__ p, float* __restrict__ gp, int R, int Cc) {
+    __shared__ float red[2][4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const bool ok = col < Cc;
+    const long long base = (long long)b * R * Cc + col;
+    float c = 0.f, d = 0.f;
+    if (ok) for (int r = rg; r < R; r += 4) {
+        const long long o = base + (long long)r * Cc;
+        c += p[o] * dp[o];
+        d += gs[o] * p[o];
+    }
+    red[0][rg][cl] = c;
+    red[1][rg][cl] = d;
+    __syncthreads();
+    c = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    d = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    if (!ok) return;
+    for (int r = rg; r < R; r += 4) {
+        const long long o = base + (long long)r * Cc;
+        gp[o] = gs[o] * (dp[o] - c) - dp[o] * d;
+    }
+}
+extern "C" int gim_softmax_dim1_bwd_dp(const float* gs, const float* dp, const float* p, float* gp, int B, int R, int Ccols, void* stream) {
+    GIM_CHECK_ARG(gs && dp && p && gp && B > 0 && R > 0 && Ccols > 0, "softmax_dim1_bwd_dp: bad args");
+    hipLaunchKernelGGL(softmax_dim1_bwd_dp_kernel, dim3((Ccols + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, gs, dp, p, gp, R, Ccols);
+    return gim_check_launch("gim_softmax_dim1_bwd_dp");
+}
+
+// second-order set statistics.  First-order backward: dx_j = dm/t + ds * (x_j - m) / ((t-1) sd).
+// Given g (same shape as dx): adjoint w.r.t. (dm, ds):  g_dm = sum_j g_j / t,  g_ds = sum_j g_j (x_j - m) / ((t-1) sd);
+// w.r.t. x: gx_k = ds/((t-1) sd) * [ g_k - mean(g) - (x_k - m) * sum_j g_j (x_j - m) / ((t-1) sd^2) ]
+__global__ __launch_bounds__(256) void set_stats_bwd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ds, const float* __restrict__ g,
+                                                                float* __restrict__ g_dm, float* __restrict__ g_ds, float* __restrict__ gx,
+                                                                int B, int t, int D, long long ld_in, long long ld_out) {
+    const long long n = (long long)B * D;
+    GRID_STRIDE(i, n) {
+        const int d = (int)(i % D);
+        const long long b = i / D;
+        const float* xb = x + b * t * D + d;
+        const float* gb = g + b * t * D + d;
+        float m = 0.f, gsum = 0.f;
+        for (int j = 0; j < t; ++j) { m += xb[(long long)j * D]; gsum += gb[(long long)j * D]; }
+        m /= (float)t;
+        if (g_dm) g_dm[b * ld_out + d] = gsum / (float)t;
+        float sdv = 0.f, gdot = 0.f, coef = 0.f;
+        if (t > 1) {
+            float ss = 0.f;
+            for (int j = 0; j < t; ++j) { const float dd = xb[(long long)j * D] - m; ss += dd * dd; gdot += gb[(long long)j * D] * dd; }
+            sdv = sqrtf(ss / (float)(t - 1) + 1e-8f);
+            coef = 1.0f / ((float)(t - 1) * sdv);
+        }
+        if (g_ds) g_ds[b * ld_out + d] = gdot * coef;
+        if (gx) {
+            float* ob = gx + b * t * D + d;
+            const float dsv = (ds && t > 1) ? ds[b * ld_in + d] : 0.f;
+            const float k2 = (t > 1) ? gdot * coef / sdv : 0.f;  // sum_j g_j (x_j - m) / ((t-1) sd^2)
+            for (int j = 0; j < t; ++j)
+                ob[(long long)j * D] = dsv * coef * (gb[(long long)j * D] - gsum / (float)t - (xb[(long long)j * D] - m) * k2);
+        }
+    }
+}
+extern "C" int gim_set_stats_bwd_bwd(const float* x, const float* dstd, const float* g, float* g_dmean, float* g_dstd, float* gx, int B,
+                                     int t, int D, int64_t ld_dstd, int64_t ld_out, void* stream) {
+    GIM_CHECK_ARG(x && g && B > 0 && t > 0 && D > 0, "set_stats_bwd_bwd: bad args");
+    hipLaunchKernelGGL(set_stats_bwd_bwd_kernel, dim3(pw_blocks((long long)B * D)), dim3(256), 0, (hipStream_t)stream, x, dstd, g, g_dmean,
+                       g_dstd, gx, B, t, D, (long long)ld_dstd, (long long)ld_out);
+    return gim_check_launch("gim_set_stats_bwd_bwd");
+}
+
+// per-episode squared norm: out[b] = sum_i x[b][i]^2 (training/utils.py:122-123), and its gradient 2 * x * dout[b]
+__global__ __launch_bounds__(256) void sqsum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, long long L) {
+    __shared__ float red[4];
+    const float* xb = x + (long long)blockIdx.x * L;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < L; i += 256) s += xb[i] * xb[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sqsum_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dx,
+                                                             long long B, long long L) {
+    const long long n = B * L;
+    GRID_STRIDE(i, n) dx[i] = 2.0f * x[i] * dout[i / L];
+}
+extern "C" int gim_sqsum_rows_fwd(const float* x, float* out, int B, int64_t L, void* stream) {
+    GIM_CHECK_ARG(x && out && B > 0 && L > 0, "sqsum_rows_fwd: bad args");
+    hipLaunchKernelGGL(sqsum_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, out, (long long)L);
+    return gim_check_launch("gim_sqsum_rows_fwd");
+}
+extern "C" int gim_sqsum_rows_bwd(const float* x, const float* dout, float* dx, int B, int64_t L, void* stream) {
+    GIM_CHECK_ARG(x && dout && dx && B > 0 && L > 0, "sqsum_rows_bwd: bad args");
+    hipLaunchKernelGGL(sqsum_rows_bwd_kernel, dim3(pw_blocks((long long)B * L)), dim3(256), 0, (hipStream_t)stream, x, dout, dx, (long long)B,
+                       (long long)L);
+    return gim_check_launch("gim_sqsum_rows_bwd");
+}
+
+// out = g * lrelu'(x)  (the activation mask of a fused-prologue conv, applied to a second-order cotangent)
+__global__ __launch_bounds__(256) void lrelu_mask_mul_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ out,
+                                                             long long n, float slope) {
+    GRID_STRIDE(i, n) out[i] = g[i] * (x[i] > 0.f ? 1.0f : slope);
+}
+extern "C" int gim_lrelu_mask_mul(const float* g, const float* x, float slope, float* out, int64_t n, void* stream) {
+    GIM_CHECK_ARG(g && x && out && n > 0, "lrelu_mask_mul: bad args");
+    hipLaunchKernelGGL(lrelu_mask_mul_kernel, dim3(pw_blocks((long long)n)), dim3(256), 0, (hipStream_t)stream, g, x, out, (long long)n, slope);
+    return gim_check_launch("gim_lrelu_mask_mul");
+}

@@ -1,6 +1,5 @@
 """GIMGaussianTrainer (training/gim_gaussian_trainer.py:20-150) on the engine: same constructor, forward modes and
-return tuples as the reference; FusedAdam with torch.optim.Adam's default betas.  reg_param > 0 (R1) is not on the
-accelerated path yet."""
+return tuples as the reference (R1 term included); FusedAdam with torch.optim.Adam's default betas."""
 import os
 
 import torch
@@ -9,7 +8,7 @@ import torch.nn as nn
 from . import ops
 from .gim_img_trainer import _frozen
 from .optim import FusedAdam
-from .training_utils import CheckpointIO, GlobalStep, num_parameters
+from .training_utils import CheckpointIO, GlobalStep, compute_grad2, num_parameters
 
 
 class GIMGaussianTrainer(nn.Module):
@@ -50,11 +49,15 @@ class GIMGaussianTrainer(nn.Module):
         return loss.squeeze()
 
     def authenticator_forward(self, fake_sample, real_sample, si_sample, grad=True):
-        if grad and self.reg_param > 0:
-            raise NotImplementedError("reg_param > 0 (R1 double backward) is not on the accelerated path yet; use reg_param=0")
+        if self.reg_param > 0:
+            real_sample.requires_grad_()
+            si_sample.requires_grad_()
         out_on_real = self.authenticator(test_sample=real_sample, si_sample=si_sample)
         loss_on_real = self.gan_loss(dis_out=out_on_real, target=1.)
-        reg = torch.zeros_like(loss_on_real)
+        if grad and self.reg_param > 0:
+            reg = self.reg_param * compute_grad2(out_on_real, (real_sample, si_sample))
+        else:
+            reg = torch.zeros_like(loss_on_real)
         out_on_fake = self.authenticator(test_sample=fake_sample, si_sample=si_sample)
         loss_on_fake = self.gan_loss(dis_out=out_on_fake, target=0.)
         with torch.no_grad():

@@ -7,7 +7,8 @@ Differences that do not change any result of the training loop:
   * in ``impersonator_forward`` the authenticator's parameters are frozen for the duration of the forward, so
     the generator step does not compute the discriminator weight gradients that the reference computes and
     then discards (``authenticator_opt.zero_grad()`` at training/gim_img_training.py:172) - SURVEY.md 8(a);
-  * ``reg_param > 0`` (R1 double backward) is not on the accelerated path yet and raises.
+  * the R1 term (``reg_param > 0``) differentiates the authenticator's input gradient through the same HIP kernels
+    (ops.ConvDgradFn and friends); no torch operator is on that path either.
 """
 import os
 from contextlib import contextmanager
@@ -18,7 +19,7 @@ import torch.optim as optim
 
 from . import ops
 from .optim import FusedAdam
-from .training_utils import CheckpointIO, GlobalStep, num_parameters
+from .training_utils import CheckpointIO, GlobalStep, compute_grad2, num_parameters
 
 
 @contextmanager
@@ -90,8 +91,9 @@ class GIMImgTrainer(nn.Module):
         return loss.squeeze()
 
     def authenticator_forward(self, fake_sample, real_sample, si_sample, grad=True):
-        if grad and self.reg_param > 0:
-            raise NotImplementedError("reg_param > 0 (R1 double backward) is not on the accelerated path yet; use reg_param=0")
+        if self.reg_param > 0:  # training/gim_img_trainer.py:98-100
+            real_sample.requires_grad_()
+            si_sample.requires_grad_()
 
         self.authenticator.prefetch_spectral(3)  # si, real, fake: three calls of each encoder
         # same per-encoder call order as the reference (si, real, fake); the two encoders run on two streams
@@ -100,7 +102,10 @@ class GIMImgTrainer(nn.Module):
 
         out_on_real = self.authenticator.dis(test_src=au_real_src, test_env=au_real_env, si_src=au_si_src, si_env=au_si_env)
         loss_on_real = self.gan_loss(dis_out=out_on_real, target=1.)
-        reg = torch.zeros_like(loss_on_real)
+        if grad and self.reg_param > 0:
+            reg = self.reg_param * compute_grad2(out_on_real, (real_sample, si_sample))
+        else:
+            reg = torch.zeros_like(loss_on_real)
 
         out_on_fake = self.authenticator.dis(test_src=au_fake_src, test_env=au_fake_env, si_src=au_si_src, si_env=au_si_env)
         loss_on_fake = self.gan_loss(dis_out=out_on_fake, target=0.)

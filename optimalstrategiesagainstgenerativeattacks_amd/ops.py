@@ -6,11 +6,38 @@ must be CUDA(HIP) float32.  Activations are NHWC.
 """
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import GimConvShape, check
 
 LRELU_SLOPE = 0.2
+
+# Higher-order mode.  The only second-order quantity of the training path is the R1 regulariser
+# (training/utils.py:115-124): the gradient of the authenticator's output w.r.t. its INPUT IMAGES, differentiated
+# once more w.r.t. the parameters.  Inside `input_grad_only()` a backward that runs with create_graph=True returns
+# differentiable input gradients (each first-order backward is itself a Function whose adjoint reuses the same
+# kernels) and no parameter gradients; create_graph outside that context is refused rather than silently wrong.
+_HIGHER = {"input_grad_only": False}
+
+
+class input_grad_only:
+    def __enter__(self):
+        self.prev = _HIGHER["input_grad_only"]
+        _HIGHER["input_grad_only"] = True
+
+    def __exit__(self, *exc):
+        _HIGHER["input_grad_only"] = self.prev
+
+
+def _second_order():
+    """True when this backward is being recorded (create_graph=True)."""
+    if not torch.is_grad_enabled():
+        return False
+    if not _HIGHER["input_grad_only"]:
+        raise NotImplementedError("create_graph=True is supported for input gradients only: wrap the autograd.grad call in "
+                                  "ops.input_grad_only() (training_utils.compute_grad2 does)")
+    return True
 
 
 def _stream():
@@ -114,54 +141,23 @@ class ConvFn(Function):
         x, w, sigma, u_s, v_s, wf, bias = ctx.saved_tensors
         N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = ctx.cfg
         dy = _req(dy, "dy")
+        if _second_order():
+            if ups or res_ups:
+                raise NotImplementedError("second-order backward of an upsampling convolution is not on the R1 path")
+            dx = ConvDgradFn.apply(dy, w, x, sigma, u_s, v_s, wf, ctx.cfg) if ctx.needs_input_grad[0] else None
+            return dx, None, None, (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None, None, None, None, None
         wp = weight_phys(w)
         sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
         st = _stream()
         dev = dy.device
         dx = dw = db = dres = None
-        mask = x if pre_slope != 1.0 else None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            wk = wf if fold else wp
-            if ups and not fold:
-                dxu = torch.empty((N, H, W, Cin), device=dev, dtype=torch.float32)
-                check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), None, _p(dxu), sh, st), "conv2d_dgrad")
-                check(lib.gim_upsample2x_bwd(_p(dxu), _p(mask), pre_slope, _p(dx), N, H >> 1, W >> 1, Cin, st), "upsample2x_bwd")
-            else:
-                check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad")
+            dx = _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, ctx.cfg, st)
         want_w = ctx.needs_input_grad[1]
         want_b = has_bias and ctx.needs_input_grad[2]
         Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
         if want_w:
-            ns = lib.gim_conv2d_wgrad_slabs(sh)
-            if ns <= 0:
-                check(ns, "conv2d_wgrad_slabs")
-            K = KH * KH * Cin
-            KFF = (KH + 1) * (KH + 1) * Cin if fold else K
-            dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
-            slab_bias = want_b and not (fold and ups)  # the role-swapped sub-pixel wgrad does not stream dy as its A operand
-            # Megatron-style direct accumulation: when the parameter's .grad already exists as a dense buffer in the
-            # weight's own memory order (FusedAdam's flat gradient bucket) and no higher-order graph is being built,
-            # the finish kernels ADD into it and autograd gets None (no AccumulateGrad add kernel per parameter).
-            acc_w = _grad_target(w) if (sigma is not None or not fold) and not torch.is_grad_enabled() else None
-            acc_b = _grad_target(bias) if (slab_bias and acc_w is not None) else None
-            if want_b and acc_b is None:
-                db = torch.empty(Cout, device=dev, dtype=torch.float32)
-            if ns == 1 and sigma is None and not fold and acc_w is None:
-                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(dwp), _p(db) if slab_bias else None, 1, sh, st), "conv2d_wgrad")
-            else:
-                slabs = torch.empty(ns * Cout * KFF, device=dev, dtype=torch.float32)
-                bslabs = torch.empty(ns * Cout, device=dev, dtype=torch.float32) if slab_bias else None
-                scratch = torch.empty(512 + (Cout * KFF if fold else 0), device=dev, dtype=torch.float32)
-                check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(slabs), _p(bslabs), ns, sh, st), "conv2d_wgrad")
-                check(lib.gim_wgrad_finish(_p(slabs), _p(bslabs), ns, _p(wp), _p(sigma), _p(u_s), _p(v_s), _p(dwp),
-                                           _p(db) if (slab_bias and acc_b is None) else None, _p(scratch), Cout, Cin, KH,
-                                           (2 if ups else 1) if fold else 0, _p(acc_w), _p(acc_b), st), "wgrad_finish")
-            if want_b and not slab_bias:
-                scr = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
-                check(lib.gim_colsum(_p(dy), _p(db), _p(scr), Mo, Cout, st), "colsum")
-            if acc_w is None:
-                dw = dwp.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2) if w.dim() == 4 else dwp.view(Cout, Cin)
+            dw, db = _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, ctx.cfg, want_b, st)
         elif want_b:
             db = torch.empty(Cout, device=dev, dtype=torch.float32)
             scratch = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
@@ -173,6 +169,101 @@ class ConvFn(Function):
             else:
                 dres = dy
         return dx, dw, db, dres, None, None, None, None, None, None, None, None
+
+
+def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st):
+    """dx = lrelu'(x) * dgrad(dy, w) / sigma  (through the pool / sub-pixel folds when the forward used them)."""
+    N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
+    mask = x if pre_slope != 1.0 else None
+    dx = torch.empty_like(x)
+    wk = wf if fold else wp
+    if ups and not fold:
+        dxu = torch.empty((N, H, W, Cin), device=dy.device, dtype=torch.float32)
+        check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), None, _p(dxu), sh, st), "conv2d_dgrad")
+        check(lib.gim_upsample2x_bwd(_p(dxu), _p(mask), pre_slope, _p(dx), N, H >> 1, W >> 1, Cin, st), "upsample2x_bwd")
+    else:
+        check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad")
+    return dx
+
+
+def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
+    """(dw, db) of one convolution; either may come back None because it was ADDED into the parameter's .grad."""
+    N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
+    dev = dy.device
+    dw = db = None
+    Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
+    ns = lib.gim_conv2d_wgrad_slabs(sh)
+    if ns <= 0:
+        check(ns, "conv2d_wgrad_slabs")
+    K = KH * KH * Cin
+    KFF = (KH + 1) * (KH + 1) * Cin if fold else K
+    dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
+    slab_bias = want_b and not (fold and ups)  # the role-swapped sub-pixel wgrad does not stream dy as its A operand
+    # Megatron-style direct accumulation: when the parameter's .grad already exists as a dense buffer in the
+    # weight's own memory order (FusedAdam's flat gradient bucket) and no higher-order graph is being built,
+    # the finish kernels ADD into it and autograd gets None (no AccumulateGrad add kernel per parameter).
+    acc_w = _grad_target(w) if (sigma is not None or not fold) and not torch.is_grad_enabled() else None
+    acc_b = _grad_target(bias) if (slab_bias and acc_w is not None) else None
+    if want_b and acc_b is None:
+        db = torch.empty(Cout, device=dev, dtype=torch.float32)
+    if ns == 1 and sigma is None and not fold and acc_w is None:
+        check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(dwp), _p(db) if slab_bias else None, 1, sh, st), "conv2d_wgrad")
+    else:
+        slabs = torch.empty(ns * Cout * KFF, device=dev, dtype=torch.float32)
+        bslabs = torch.empty(ns * Cout, device=dev, dtype=torch.float32) if slab_bias else None
+        scratch = torch.empty(512 + (Cout * KFF if fold else 0), device=dev, dtype=torch.float32)
+        check(lib.gim_conv2d_wgrad(_p(dy), _p(x), _p(slabs), _p(bslabs), ns, sh, st), "conv2d_wgrad")
+        check(lib.gim_wgrad_finish(_p(slabs), _p(bslabs), ns, _p(wp), _p(sigma), _p(u_s), _p(v_s), _p(dwp),
+                                   _p(db) if (slab_bias and acc_b is None) else None, _p(scratch), Cout, Cin, KH,
+                                   (2 if ups else 1) if fold else 0, _p(acc_w), _p(acc_b), st), "wgrad_finish")
+    if want_b and not slab_bias:
+        scr = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
+        check(lib.gim_colsum(_p(dy), _p(db), _p(scr), Mo, Cout, st), "colsum")
+    if acc_w is None:
+        dw = dwp.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2) if w.dim() == 4 else dwp.view(Cout, Cin)
+    return dw, db
+
+
+class ConvDgradFn(Function):
+    """The first-order input gradient of ConvFn as an operator of (dy, w):  dx = lrelu'(x) * conv^T(dy, w / sigma(w)).
+    It is bilinear in (dy, w/sigma), so its own adjoints are the other two kernels of the same convolution:
+    d/d(dy) is the FORWARD conv of the masked cotangent and d/dw is the WGRAD with that cotangent in the role of
+    the layer input (followed by the same spectral-norm chain rule).  The mask is piecewise constant in x."""
+
+    @staticmethod
+    def forward(ctx, dy, w, x, sigma, u_s, v_s, wf, cfg):
+        lib = _lib.load()
+        N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
+        sh = _shape(N, H, W, Cin, Cout, KH, 0, pre_slope, 1 if pool else 0, fold, 0)
+        dx = _conv_dgrad(lib, dy, x, weight_phys(w), wf, sigma, sh, cfg, _stream())
+        ctx.save_for_backward(dy, w, x, sigma, u_s, v_s, wf)
+        ctx.cfg = cfg
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        dy, w, x, sigma, u_s, v_s, wf = ctx.saved_tensors
+        N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = ctx.cfg
+        if torch.is_grad_enabled():
+            raise NotImplementedError("third-order gradients are not supported")
+        g = _req(g, "g")
+        st = _stream()
+        wp = weight_phys(w)
+        if pre_slope != 1.0:
+            gm = torch.empty_like(g)
+            check(lib.gim_lrelu_mask_mul(_p(g), _p(x), pre_slope, _p(gm), g.numel(), st), "lrelu_mask_mul")
+        else:
+            gm = g
+        lin = (N, H, W, Cin, Cout, KH, 0, 1.0, False, False, pool, fold, False)   # the conv as a linear map: no prologue, bias, residual
+        sh = _shape(N, H, W, Cin, Cout, KH, 0, 1.0, 1 if pool else 0, fold, 0)
+        g_dy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_dy = torch.empty_like(dy)
+            check(lib.gim_conv2d_fwd(_p(gm), _p(wf if fold else wp), None, _p(sigma), None, _p(g_dy), sh, st), "conv2d_fwd")
+        if ctx.needs_input_grad[1]:
+            g_w, _ = _conv_wgrad(lib, dy, gm, w, wp, None, sigma, u_s, v_s, sh, lin, False, st)
+        return g_dy, g_w, None, None, None, None, None, None
 
 
 def _grad_target(p):
@@ -227,6 +318,7 @@ class NormFn(Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         lib = _lib.load()
         x, scale, stats = ctx.saved_tensors
@@ -272,12 +364,24 @@ class AvgPool2Fn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        return AvgPool2BwdFn.apply(dy, ctx.cfg)
+
+
+class AvgPool2BwdFn(Function):
+    """dx of the 2x2 average pool (a linear map; its adjoint is the pool itself)."""
+
+    @staticmethod
+    def forward(ctx, dy, cfg):
         lib = _lib.load()
-        N, H, W, C = ctx.cfg
+        N, H, W, C = cfg
         dy = _req(dy, "dy")
         dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
         check(lib.gim_avgpool2_bwd(_p(dy), _p(dx), N, H, W, C, _stream()), "avgpool2_bwd")
         return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        return AvgPool2Fn.apply(g), None
 
 
 class MaxPoolLreluFn(Function):
@@ -297,13 +401,33 @@ class MaxPoolLreluFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _lib.load()
         y, idx = ctx.saved_tensors
-        N, H, W, C = ctx.cfg
+        return MaxPoolLreluBwdFn.apply(dy, y.detach(), idx, ctx.cfg)
+
+
+class MaxPoolLreluBwdFn(Function):
+    """dx of MaxPoolLreluFn: routes lrelu'(y) * dy to the arg-max pixel (linear in dy; routing is piecewise constant)."""
+
+    @staticmethod
+    def forward(ctx, dy, y, idx, cfg):
+        lib = _lib.load()
+        N, H, W, C = cfg
         dy = _req(dy, "dy")
         dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
         check(lib.gim_maxpool_lrelu_bwd(_p(dy), _p(y), idx.data_ptr(), _p(dx), N, H * W, C, LRELU_SLOPE, _stream()), "maxpool_lrelu_bwd")
+        ctx.save_for_backward(y, idx)
+        ctx.cfg = cfg
         return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y, idx = ctx.saved_tensors
+        N, H, W, C = ctx.cfg
+        g = _req(g, "g")
+        gdy = torch.empty((N, C), device=g.device, dtype=torch.float32)
+        check(lib.gim_maxpool_gather(_p(g), _p(y), idx.data_ptr(), _p(gdy), N, H * W, C, LRELU_SLOPE, _stream()), "maxpool_gather")
+        return gdy, None, None, None
 
 
 class TanhFn(Function):
@@ -317,6 +441,7 @@ class TanhFn(Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         lib = _lib.load()
         (y,) = ctx.saved_tensors
@@ -343,11 +468,40 @@ class ScaleAddFn(Function):
         lib = _lib.load()
         a, gamma = ctx.saved_tensors
         dy = _req(dy, "dy")
+        if _second_order():
+            return (MulScalarFn.apply(dy, gamma) if ctx.needs_input_grad[0] else None), dy, None
         da = torch.empty_like(a)
         dg = torch.empty(1, device=dy.device, dtype=torch.float32)
         scratch = torch.empty(2048, device=dy.device, dtype=torch.float32)
         check(lib.gim_scale_add_bwd(_p(dy), _p(a), _p(gamma), _p(da), _p(dg), _p(scratch), a.numel(), _stream()), "scale_add_bwd")
         return da, dy, dg.view_as(gamma)
+
+
+class MulScalarFn(Function):
+    """y = gamma * x with gamma a 1-element tensor (the attention branch of ScaleAddFn's backward, made differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma):
+        y, _ = MulScalarFn._run(x, x, gamma)
+        ctx.save_for_backward(x, gamma)
+        return y
+
+    @staticmethod
+    def _run(dy, a, gamma):
+        """(gamma * dy, sum(dy * a)) - one launch of the scale_add backward kernel."""
+        lib = _lib.load()
+        dy, a = _req(dy, "dy"), _req(a, "a")
+        da = torch.empty_like(dy)
+        dg = torch.empty(1, device=dy.device, dtype=torch.float32)
+        scratch = torch.empty(2048, device=dy.device, dtype=torch.float32)
+        check(lib.gim_scale_add_bwd(_p(dy), _p(a), _p(gamma), _p(da), _p(dg), _p(scratch), a.numel(), _stream()), "scale_add_bwd")
+        return da, dg
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma = ctx.saved_tensors
+        gx, gg = MulScalarFn._run(g, x, gamma)
+        return gx, gg.view_as(gamma)
 
 
 class ToNHWCFn(Function):
@@ -367,14 +521,7 @@ class ToNHWCFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _lib.load()
-        N, C, H, W = ctx.cfg
-        dy = _req(dy, "dy")
-        if C == 1:
-            return dy.view(N, 1, H, W)
-        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
-        check(lib.gim_nhwc_to_nchw(_p(dy), _p(dx), N, C, H * W, _stream()), "nhwc_to_nchw")
-        return dx
+        return ToNCHWFn.apply(dy)
 
 
 class ToNCHWFn(Function):
@@ -394,14 +541,7 @@ class ToNCHWFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _lib.load()
-        N, C, H, W = ctx.cfg
-        dy = _req(dy, "dy")
-        if C == 1:
-            return dy.view(N, H, W, 1)
-        dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
-        check(lib.gim_nchw_to_nhwc(_p(dy), _p(dx), N, C, H * W, _stream()), "nchw_to_nhwc")
-        return dx
+        return ToNHWCFn.apply(dy)
 
 
 # --------------------------------------------------------------------------------------------
@@ -411,44 +551,90 @@ def _bgemm(A, B, C, batch, M, N, K, sA, sB):
     check(_lib.load().gim_bgemm(_p(A), _p(B), _p(C), batch, M, N, K, sA[0], sA[1], sA[2], sB[0], sB[1], sB[2], _stream()), "bgemm")
 
 
-class AttnCoreFn(Function):
+class BgemmFn(Function):
+    """C[b] = op(A[b]) @ op(B[b]) for contiguous [batch, rows, cols] operands, op = transpose when tA / tB.
+    Bilinear: its backward is two more batched GEMMs, expressed through BgemmFn so that they are differentiable too."""
+
+    @staticmethod
+    def forward(ctx, A, B, tA, tB):
+        A, B = _req(A, "A"), _req(B, "B")
+        nb, ra, ca = A.shape
+        _, rb, cb = B.shape
+        M, K = (ca, ra) if tA else (ra, ca)
+        K2, N = (cb, rb) if tB else (rb, cb)
+        if K != K2 or B.shape[0] != nb:
+            raise RuntimeError("bgemm: inner dimensions differ (%s %s, tA=%d tB=%d)" % (tuple(A.shape), tuple(B.shape), tA, tB))
+        C = torch.empty((nb, M, N), device=A.device, dtype=torch.float32)
+        _bgemm(A, B, C, nb, M, N, K, (ra * ca, 1, ca) if tA else (ra * ca, ca, 1), (rb * cb, 1, cb) if tB else (rb * cb, cb, 1))
+        ctx.save_for_backward(A, B)
+        ctx.t = (tA, tB)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        tA, tB = ctx.t
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            # C = A op(B): dA = dC op(B)^T ;  C = A^T op(B): dA = op(B) dC^T
+            dA = BgemmFn.apply(B, dC, tB, 1) if tA else BgemmFn.apply(dC, B, 0, 1 - tB)
+        if ctx.needs_input_grad[1]:
+            # C = op(A) B: dB = op(A)^T dC ;  C = op(A) B^T: dB = dC^T op(A)
+            dB = BgemmFn.apply(dC, A, 1, tA) if tB else BgemmFn.apply(A, dC, 1 - tA, 0)
+        return dA, dB, None, None
+
+
+class SoftmaxDim1Fn(Function):
+    """softmax over dim 1 of [B, R, C] (the reference's attention normalises over the key index, dim -2)."""
+
+    @staticmethod
+    def forward(ctx, S):
+        S = _req(S, "S")
+        Nb, R, C = S.shape
+        P = torch.empty_like(S)
+        check(_lib.load().gim_softmax_dim1_fwd(_p(S), _p(P), Nb, R, C, _stream()), "softmax_dim1_fwd")
+        ctx.save_for_backward(P)
+        return P
+
+    @staticmethod
+    def backward(ctx, dP):
+        (P,) = ctx.saved_tensors
+        return SoftmaxDim1BwdFn.apply(dP, P)
+
+
+class SoftmaxDim1BwdFn(Function):
+    """dS = P * (dP - colsum(P * dP)) as an operator of (dP, P)."""
+
+    @staticmethod
+    def forward(ctx, dP, P):
+        dP, P = _req(dP, "dP"), _req(P, "P")
+        Nb, R, C = P.shape
+        dS = torch.empty_like(P)
+        check(_lib.load().gim_softmax_dim1_bwd(_p(dP), _p(P), _p(dS), Nb, R, C, _stream()), "softmax_dim1_bwd")
+        ctx.save_for_backward(dP, P)
+        return dS
+
+    @staticmethod
+    def backward(ctx, gS):
+        lib = _lib.load()
+        dP, P = ctx.saved_tensors
+        gS = _req(gS, "gS")
+        Nb, R, C = P.shape
+        g_dP = g_P = None
+        if ctx.needs_input_grad[0]:   # the Jacobian w.r.t. dP is symmetric
+            g_dP = torch.empty_like(P)
+            check(lib.gim_softmax_dim1_bwd(_p(gS), _p(P), _p(g_dP), Nb, R, C, _stream()), "softmax_dim1_bwd")
+        if ctx.needs_input_grad[1]:
+            g_P = torch.empty_like(P)
+            check(lib.gim_softmax_dim1_bwd_dp(_p(gS), _p(dP), _p(P), _p(g_P), Nb, R, C, _stream()), "softmax_dim1_bwd_dp")
+        return g_dP, g_P
+
+
+def attn_core(f, g, h):
     """out[b, j, :] = sum_i softmax_i(f[b,i,:] . g[b,j,:]) * h[b,i,:]   (tokens = pixels, NHWC rows)."""
-
-    @staticmethod
-    def forward(ctx, f, g, h):
-        lib = _lib.load()
-        f, g, h = _req(f, "f"), _req(g, "g"), _req(h, "h")
-        Nb, P, Cq = f.shape
-        C = h.shape[2]
-        dev = f.device
-        S = torch.empty((Nb, P, P), device=dev, dtype=torch.float32)
-        _bgemm(f, g, S, Nb, P, P, Cq, (P * Cq, Cq, 1), (P * Cq, 1, Cq))
-        A = torch.empty_like(S)
-        check(lib.gim_softmax_dim1_fwd(_p(S), _p(A), Nb, P, P, _stream()), "softmax_dim1_fwd")
-        out = torch.empty((Nb, P, C), device=dev, dtype=torch.float32)
-        _bgemm(A, h, out, Nb, P, C, P, (P * P, 1, P), (P * C, C, 1))
-        ctx.save_for_backward(f, g, h, A)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        lib = _lib.load()
-        f, g, h, A = ctx.saved_tensors
-        dout = _req(dout, "dout")
-        Nb, P, Cq = f.shape
-        C = h.shape[2]
-        dev = f.device
-        dh = torch.empty_like(h)
-        _bgemm(A, dout, dh, Nb, P, C, P, (P * P, P, 1), (P * C, C, 1))
-        dA = torch.empty_like(A)
-        _bgemm(h, dout, dA, Nb, P, P, C, (P * C, C, 1), (P * C, 1, C))
-        dS = torch.empty_like(A)
-        check(lib.gim_softmax_dim1_bwd(_p(dA), _p(A), _p(dS), Nb, P, P, _stream()), "softmax_dim1_bwd")
-        df = torch.empty_like(f)
-        _bgemm(dS, g, df, Nb, P, Cq, P, (P * P, P, 1), (P * Cq, Cq, 1))
-        dg = torch.empty_like(g)
-        _bgemm(dS, f, dg, Nb, P, Cq, P, (P * P, 1, P), (P * Cq, Cq, 1))
-        return df, dg, dh
+    S = BgemmFn.apply(f, g, 0, 1)        # S[i, j] = f_i . g_j
+    A = SoftmaxDim1Fn.apply(S)
+    return BgemmFn.apply(A, h, 1, 0)     # out = A^T h
 
 
 # --------------------------------------------------------------------------------------------
@@ -468,6 +654,7 @@ class SumDim1Fn(Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         lib = _lib.load()
         B, t, D, scale = ctx.cfg
@@ -491,6 +678,7 @@ class RepeatDim1Fn(Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         lib = _lib.load()
         B, t, D = ctx.cfg
@@ -518,6 +706,7 @@ class NoiseCombineFn(Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         lib = _lib.load()
         B, t, D, remove_mean = ctx.cfg
@@ -546,6 +735,7 @@ class Concat2Fn(Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         lib = _lib.load()
         Ni, H, W, Ca, Cb = ctx.cfg
@@ -603,8 +793,13 @@ class HeadCatFn(Function):
         need = ctx.needs_input_grad
         grads = [None] * 6
 
+        second = _second_order()
+
         def bwd(i, x, t, D, o_mean, o_std):
             if not need[i]:
+                return
+            if second:
+                grads[i] = SetStatsBwdFn.apply(dout, x, o_mean, o_std)
                 return
             dx = torch.empty_like(x)
             check(lib.gim_set_stats_bwd(_p(x), _p(dout, o_mean), (_p(dout, o_std) if o_std is not None else None), _p(dx),
@@ -618,6 +813,65 @@ class HeadCatFn(Function):
         bwd(4, ft, n, Df, o_te + 2 * De, None)
         bwd(5, fs, k, Df, o_se + 2 * De, None)
         return tuple(grads)
+
+
+class SetStatsBwdFn(Function):
+    """dx[b, j] = dout[b, o_mean:] / t + dout[b, o_std:] * (x[b, j] - mean) / ((t - 1) * custom_std)  as an operator of (dout, x):
+    the backward of one mean / [mean, custom_std] slot of the authenticator head, differentiable for the R1 term."""
+
+    @staticmethod
+    def forward(ctx, dout, x, o_mean, o_std):
+        dout, x = _req(dout, "dout"), _req(x, "x")
+        B, t, D = x.shape
+        L = dout.shape[1]
+        dx = torch.empty_like(x)
+        check(_lib.load().gim_set_stats_bwd(_p(x), _p(dout, o_mean), (_p(dout, o_std) if o_std is not None else None), _p(dx),
+                                            B, t, D, L, L, _stream()), "set_stats_bwd")
+        ctx.save_for_backward(dout, x)
+        ctx.o = (o_mean, o_std)
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        dout, x = ctx.saved_tensors
+        o_mean, o_std = ctx.o
+        g = _req(g, "g")
+        B, t, D = x.shape
+        L = dout.shape[1]
+        g_dout = torch.zeros_like(dout) if ctx.needs_input_grad[0] else None
+        gx = torch.empty_like(x) if (ctx.needs_input_grad[1] and o_std is not None) else None
+        check(_lib.load().gim_set_stats_bwd_bwd(_p(x), (_p(dout, o_std) if o_std is not None else None), _p(g),
+                                                (_p(g_dout, o_mean) if g_dout is not None else None),
+                                                (_p(g_dout, o_std) if (g_dout is not None and o_std is not None) else None),
+                                                _p(gx), B, t, D, L, L, _stream()), "set_stats_bwd_bwd")
+        return g_dout, gx, None, None
+
+
+class SqSumRowsFn(Function):
+    """out[b] = sum_i x[b, i]^2  (the g.pow(2).view(B, -1).sum(1) of compute_grad2, training/utils.py:122)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "x")
+        B, L = x.shape
+        out = torch.empty(B, device=x.device, dtype=torch.float32)
+        check(_lib.load().gim_sqsum_rows_fwd(_p(x), _p(out), B, L, _stream()), "sqsum_rows_fwd")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            raise NotImplementedError("third-order gradients are not supported")
+        dout = _req(dout, "dout")
+        B, L = x.shape
+        dx = torch.empty_like(x)
+        check(_lib.load().gim_sqsum_rows_bwd(_p(x), _p(dout), _p(dx), B, L, _stream()), "sqsum_rows_bwd")
+        return dx
+
+
+sqsum_rows = SqSumRowsFn.apply
 
 
 class BCELogitsFn(Function):
@@ -634,6 +888,7 @@ class BCELogitsFn(Function):
         return loss
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dl):
         lib = _lib.load()
         (x,) = ctx.saved_tensors
@@ -649,7 +904,6 @@ tanh = TanhFn.apply
 scale_add = ScaleAddFn.apply
 to_nhwc = ToNHWCFn.apply
 to_nchw = ToNCHWFn.apply
-attn_core = AttnCoreFn.apply
 noise_combine = NoiseCombineFn.apply
 concat2 = Concat2Fn.apply
 head_cat = HeadCatFn.apply
@@ -686,9 +940,13 @@ class MeanStdCatFn(Function):
         L = dout.shape[1]
         st = _stream()
         grads = []
+        second = _second_order()
         for i, x in enumerate(xs):
             if not ctx.needs_input_grad[i]:
                 grads.append(None)
+                continue
+            if second:
+                grads.append(SetStatsBwdFn.apply(dout, x, 2 * D * i, 2 * D * i + D))
                 continue
             dx = torch.empty_like(x)
             check(lib.gim_set_stats_bwd(_p(x), _p(dout, 2 * D * i), _p(dout, 2 * D * i + D), _p(dx), B, x.shape[1], D, L, L, st), "set_stats_bwd")
@@ -715,6 +973,7 @@ class ImgAttMixFn(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         lib = _lib.load()
         q1, k1, q2, k2, x1, v2, att = ctx.saved_tensors

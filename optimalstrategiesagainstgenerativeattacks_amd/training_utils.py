@@ -9,6 +9,21 @@ import torch
 import torch.distributed as dist
 
 
+def compute_grad2(out, x_in):
+    """Per-episode squared norm of d(sum out)/d(x) summed over the tensors of x_in - the R1 term of
+    training/utils.py:115-124.  The returned [B] tensor carries a second-order graph: backward through it reaches
+    the authenticator's parameters (ops.input_grad_only documents how)."""
+    from . import ops
+    batch_size = x_in[0].size(0)
+    with ops.input_grad_only():
+        grad_out = torch.autograd.grad(outputs=out.sum(), inputs=x_in, create_graph=True, retain_graph=True, only_inputs=True)
+    reg = None
+    for g in grad_out:
+        r = ops.sqsum_rows(g.reshape(batch_size, -1))
+        reg = r if reg is None else reg + r
+    return reg
+
+
 class GlobalStep(object):
     def __init__(self, gs=-1):
         self._gs = gs
