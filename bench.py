@@ -67,13 +67,13 @@ def synthetic_batch(B, m, n, k, C, S, device, seed):
     return mk(m), mk(n), mk(k)
 
 
-def build_trainer(S, C, n, m, k, device, style_dim=512):
+def build_trainer(S, C, n, m, k, device, style_dim=512, reg_param=0.0):
     import optimalstrategiesagainstgenerativeattacks_amd as G
     torch.manual_seed(1)  # train_gim_on_imgs.py:6
     au, im = G.get_au(S, C, style_dim).to(device), G.get_im(S, C, style_dim).to(device)
     with tempfile.TemporaryDirectory() as td:
         tr = G.GIMImgTrainer(td, m, n, k, au, im, au_lr=1e-4, im_lr=1e-4, env_noise_mapping_lr=1e-6, beta1=0.0, beta2=0.99,
-                             reg_param=0.0)
+                             reg_param=reg_param)
     return G, tr
 
 
@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="episodes per GPU (default: 16 for vox64, 32 for om32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
+    ap.add_argument("--reg-param", type=float, default=0.0, help="R1 weight (BASELINE's metric is quoted at 0; 10 = the paper's VoxCeleb2 setting)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     args = ap.parse_args()
 
@@ -167,7 +168,7 @@ def main():
     m, n, k = 1, 5, 10
     u = UNIT[args.workload]
     B = args.batch or (16 if args.workload == "vox64" else 32)
-    G, tr = build_trainer(u["S"], u["C"], n, m, k, device)
+    G, tr = build_trainer(u["S"], u["C"], n, m, k, device, reg_param=args.reg_param)
     trainer = G.EpisodeParallel(tr)
     trainer.broadcast_parameters()
     leaked, real, si = synthetic_batch(B, m, n, k, u["C"], u["S"], device, 1234 + rank)
@@ -226,7 +227,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d synthetic episodes, m=%d n=%d k=%d, %d episodes/GPU, style_dim=512, "
-                                   "G step + D step + 2 Adam updates per step, reg_param=0" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B),
+                                   "G step + D step + 2 Adam updates per step, reg_param=%g" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B, args.reg_param),
                        "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world,
                        "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
