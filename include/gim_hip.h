@@ -112,6 +112,32 @@ typedef struct {
 int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, const int32_t* tab_cols, int n_col_blocks,
                                const int32_t* tab_rows, int n_row_blocks, float* out_base, int training, void* stream);
 
+/* Accumulating weight gradient: ADDS the gradient of one convolution (raw, un-finished: dW, dF or G layout as in
+ * gim_conv2d_wgrad) into `acc` / `bias_acc` with float atomics and clears nothing - the caller hands in zeroed (or
+ * partially accumulated) buffers, typically slots of one arena cleared once per backward pass. */
+int gim_conv2d_wgrad_acc(const float* dy, const float* x, float* acc, float* bias_acc, const gim_conv_shape* shape, void* stream);
+
+/* Batched form of gim_wgrad_finish for ALL convolutions / linears of one backward pass (two launches): un-fold, spectral-norm
+ * chain rule dW = G/sigma - <G,W>/sigma^2 u v^T (torch.nn.utils.spectral_norm backward; sigma == NULL: plain), ADD into
+ * grad_w / grad_b.  tab: n_blocks x {job, chunk} with chunks of 4096 elements of Cout*K*K*Cin; tab_sn: the same for the
+ * spectral-norm jobs only.  partial >= n_chunks floats; tmp >= Cout*K*K*Cin floats when fold != 0 and sigma != NULL. */
+typedef struct {
+    const float* src;
+    const float* bias_src;
+    const float* w;
+    const float* sigma;
+    const float* u;
+    const float* v;
+    float* tmp;
+    float* partial;
+    float* grad_w;
+    float* grad_b;
+    int32_t Cout, Cin, K, fold;
+    int32_t n_chunks, reserved;
+} gim_wgrad_job;
+int gim_wgrad_finish_batched(const gim_wgrad_job* jobs, int n_jobs, const int32_t* tab, int n_blocks, const int32_t* tab_sn,
+                             int n_blocks_sn, void* stream);
+
 /* Column sums: out[c] = sum_r x[r][c]  (bias gradients; rows x C). scratch >= 256*C floats. */
 int gim_colsum(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream);
 

@@ -879,14 +879,16 @@ static void launch_wgrad(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
     else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, VEC>), g, dim3(256), 0, st, p);
 }
 
-extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs,
-                                const gim_conv_shape* s, void* stream) {
+// prezeroed: the caller guarantees slabs / bias_slabs hold zeros (or a partial sum to add to): pixel slices are combined
+// with float atomics and nothing is cleared here (gim_conv2d_wgrad_acc).
+static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs, const gim_conv_shape* s,
+                      void* stream, bool prezeroed) {
     int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(dy && x && slabs, "conv wgrad: null pointer");
     const WgPlan q = wgrad_plan(s);
-    const bool atomic = g_wgrad_atomic && q.ns > 1;
-    GIM_CHECK_ARG(n_slabs == (g_wgrad_atomic ? 1 : q.ns), "conv wgrad: n_slabs must equal gim_conv2d_wgrad_slabs(shape)");
+    const bool atomic = prezeroed ? true : (g_wgrad_atomic && q.ns > 1);
+    if (!prezeroed) GIM_CHECK_ARG(n_slabs == (g_wgrad_atomic ? 1 : q.ns), "conv wgrad: n_slabs must equal gim_conv2d_wgrad_slabs(shape)");
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(up_fold && bias_slabs), "conv wgrad: the sub-pixel form does not produce the bias gradient (use gim_colsum)");
     WgP p{};
@@ -900,7 +902,7 @@ extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, f
     }
     p.slabs = slabs; p.bias_slabs = bias_slabs;
     p.M = q.M; p.Kcols = q.cols; p.mper = q.mper; p.atomic = atomic ? 1 : 0;
-    if (atomic) {
+    if (atomic && !prezeroed) {
         (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
         if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
     }
@@ -909,4 +911,13 @@ extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, f
     if (vec) launch_wgrad<4>(p, q.bm, q.bn, g, (hipStream_t)stream);
     else launch_wgrad<1>(p, q.bm, q.bn, g, (hipStream_t)stream);
     return gim_check_launch("gim_conv2d_wgrad");
+}
+
+extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs,
+                                const gim_conv_shape* s, void* stream) {
+    return wgrad_impl(dy, x, slabs, bias_slabs, n_slabs, s, stream, false);
+}
+
+extern "C" int gim_conv2d_wgrad_acc(const float* dy, const float* x, float* acc, float* bias_acc, const gim_conv_shape* s, void* stream) {
+    return wgrad_impl(dy, x, acc, bias_acc, 1, s, stream, true);
 }

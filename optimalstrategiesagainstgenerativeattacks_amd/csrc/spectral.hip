@@ -374,3 +374,92 @@ extern "C" int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, co
     hipLaunchKernelGGL(snb_final_kernel, dim3(n_jobs), dim3(256), 0, st, jobs, out_base, training);
     return gim_check_launch("gim_spectral_sigma_batched");
 }
+
+// -------------------------------------------------------------------------------------------------
+// batched weight-gradient finish: every conv / linear of one backward pass in TWO launches.
+// Each job's raw gradient was accumulated (float atomics) into a pre-zeroed arena slot by gim_conv2d_wgrad_acc; here it is
+// un-folded (pool / sub-pixel forms), pushed through the spectral-norm chain rule and ADDED into the optimizer's flat
+// gradient bucket.  One block handles WGQ_CHUNK elements of one job (table built on the host, static per model).
+// -------------------------------------------------------------------------------------------------
+#define WGQ_CHUNK 4096
+
+__device__ __forceinline__ float wgq_load(const gim_wgrad_job& jb, long long i) {
+    if (jb.fold == 0) return jb.src[i];
+    const int K = jb.K, KF = K + 1, Cin = jb.Cin, Cout = jb.Cout;
+    const int ci = (int)(i % Cin);
+    long long rr = i / Cin;
+    const int kw = (int)(rr % K); rr /= K;
+    const int kh = (int)(rr % K);
+    const int co = (int)(rr / K);
+    float g = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dwd = 0; dwd < 2; ++dwd) {
+            const int a = kh + dh, b = kw + dwd;
+            if (jb.fold == 1) g += jb.src[(((long long)co * KF + a) * KF + b) * Cin + ci];
+            else g += jb.src[(((long long)ci * KF + (K - a)) * KF + (K - b)) * Cout + co];
+        }
+    return jb.fold == 1 ? 0.25f * g : g;
+}
+
+__global__ __launch_bounds__(256) void wgq_reduce_kernel(const gim_wgrad_job* __restrict__ jobs, const int2* __restrict__ tab) {
+    __shared__ float red[4];
+    const int2 e = tab[blockIdx.x];  // {job, chunk}
+    const gim_wgrad_job jb = jobs[e.x];
+    const long long n = (long long)jb.Cout * jb.K * jb.K * jb.Cin;
+    const long long i0 = (long long)e.y * WGQ_CHUNK;
+    const bool sn = jb.sigma != nullptr;
+    float dot = 0.f;
+    for (int t = threadIdx.x; t < WGQ_CHUNK; t += 256) {
+        const long long i = i0 + t;
+        if (i >= n) break;
+        const float g = wgq_load(jb, i);
+        if (sn) {
+            if (jb.fold) jb.tmp[i] = g;
+            dot += g * jb.w[i];
+        } else {
+            atomicAdd(&jb.grad_w[i], g);  // several jobs (calls of the same conv) may target one gradient
+        }
+    }
+    if (sn) {
+        dot = block_sum_256(dot, red);
+        if (threadIdx.x == 0) jb.partial[e.y] = dot;
+    }
+    if (e.y == 0 && jb.bias_src)
+        for (int c = threadIdx.x; c < jb.Cout; c += 256) atomicAdd(&jb.grad_b[c], jb.bias_src[c]);
+}
+
+__global__ __launch_bounds__(256) void wgq_apply_kernel(const gim_wgrad_job* __restrict__ jobs, const int2* __restrict__ tab) {
+    __shared__ float red[4];
+    const int2 e = tab[blockIdx.x];
+    const gim_wgrad_job jb = jobs[e.x];
+    float d = 0.f;
+    for (int i = threadIdx.x; i < jb.n_chunks; i += 256) d += jb.partial[i];
+    d = block_sum_256(d, red);
+    const float inv = 1.0f / jb.sigma[0];
+    const float coef = d * inv * inv;
+    const int T = jb.K * jb.K, Kc = jb.Cin * T;
+    const long long n = (long long)jb.Cout * Kc;
+    const long long i0 = (long long)e.y * WGQ_CHUNK;
+    const float* __restrict__ g = jb.fold ? jb.tmp : jb.src;
+    for (int t = threadIdx.x; t < WGQ_CHUNK; t += 256) {
+        const long long i = i0 + t;
+        if (i >= n) break;
+        const int co = (int)(i / Kc);
+        const int p = (int)(i - (long long)co * Kc);
+        const int tap = p / jb.Cin, ci = p - tap * jb.Cin;
+        atomicAdd(&jb.grad_w[i], g[i] * inv - coef * jb.u[co] * jb.v[ci * T + tap]);
+    }
+}
+
+extern "C" int gim_wgrad_finish_batched(const gim_wgrad_job* jobs, int n_jobs, const int32_t* tab, int n_blocks,
+                                        const int32_t* tab_sn, int n_blocks_sn, void* stream) {
+    GIM_CHECK_ARG(jobs && n_jobs > 0 && tab && n_blocks > 0 && n_blocks_sn >= 0 && (tab_sn || n_blocks_sn == 0),
+                  "wgrad_finish_batched: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgq_reduce_kernel, dim3(n_blocks), dim3(256), 0, st, jobs, reinterpret_cast<const int2*>(tab));
+    if (n_blocks_sn > 0)
+        hipLaunchKernelGGL(wgq_apply_kernel, dim3(n_blocks_sn), dim3(256), 0, st, jobs, reinterpret_cast<const int2*>(tab_sn));
+    return gim_check_launch("gim_wgrad_finish_batched");
+}

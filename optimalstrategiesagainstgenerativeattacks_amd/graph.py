@@ -19,10 +19,11 @@ class GraphedGimStep:
     Outputs are static tensors overwritten by the next replay.  Parameters, Adam state, spectral-norm buffers are
     updated in place exactly as by the eager ``gim_step``; the host-side step counters are advanced here."""
 
-    def __init__(self, trainer, leaked, real, si, z, warmup=2):
+    def __init__(self, trainer, leaked, real, si, z, warmup=3):
         self.trainer = trainer
         self.mod = trainer.module
         self.static = [t.clone() for t in (leaked, real, si, z)]
+        warmup = max(warmup, 3)  # the batched weight-gradient finish must have seen every job table it will capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -125,12 +125,13 @@ class SNConv2d(nn.Module):
         return self._fold_cache[1]
 
     def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False):
+        guard = None
         if self._sn_queue:
-            sigma, u_s, v_s = self._sn_queue.popleft()
+            sigma, u_s, v_s, guard = self._sn_queue.popleft()
         else:
             sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
         wf = self.folded() if (pool or (ups and self.kernel_size > 1)) else None
-        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf)
+        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d (spectral norm)" % (self.in_channels, self.out_channels, self.kernel_size)
@@ -141,7 +142,12 @@ class SNPlan:
     weights and on u only, never on activations, so a forward pass that will call each conv `rounds` times runs
     `rounds` batched rounds up front (4 launches each, gim_spectral_sigma_batched) and every SNConv2d call then
     just pops its precomputed (sigma, u, v).  Sequential semantics are those of the per-call hook: round r uses
-    the u left by round r-1.  The job table is static and rebuilt only if a tensor moves."""
+    the u left by round r-1.  The job table is static and rebuilt only if a tensor moves.
+
+    The per-round outputs live in persistent buffers (two alternating sets), so their addresses are the same every
+    step - which lets the batched weight-gradient finish (ops.WgradQueue) and hipGraph capture keep static tables.
+    A backward pass that still needs a set which later forwards have overwritten (more than two forwards of the same
+    model before its backward) is refused by ops.ConvFn rather than computed from stale values."""
 
     _JOB = np.dtype([("w", "<u8"), ("u", "<u8"), ("v", "<u8"), ("off_sigma", "<i8"), ("off_u", "<i8"), ("off_v", "<i8"),
                      ("off_scratch", "<i8"), ("Cout", "<i4"), ("Cin", "<i4"), ("KH", "<i4"), ("reserved", "<i4")])
@@ -149,6 +155,12 @@ class SNPlan:
     def __init__(self, convs):
         self.convs = [c for c in convs if isinstance(c, SNConv2d)]
         self._key = None
+        self._gen = 0      # number of run() calls so far; run g writes buffer set g & 1
+        self._bufs = {}
+
+    def stale(self, gen):
+        """True when the outputs of run number `gen` have been overwritten."""
+        return self._gen - gen > 2
 
     def _build(self, key):
         dev = self.convs[0].weight_orig.device
@@ -197,13 +209,17 @@ class SNPlan:
         dev = self.convs[0].weight_orig.device
         for c in self.convs:
             c._sn_queue.clear()
-        for _ in range(rounds):
-            out = torch.empty(self._total, device=dev, dtype=torch.float32)
+        gen = self._gen
+        self._gen += 1
+        for r in range(rounds):
+            out = self._bufs.get((gen & 1, r))
+            if out is None or out.numel() != self._total or out.device != dev:
+                out = self._bufs[(gen & 1, r)] = torch.empty(self._total, device=dev, dtype=torch.float32)
             _lib.check(lib.gim_spectral_sigma_batched(self._jobs.data_ptr(), self._n[0], self._cols.data_ptr(), self._n[1],
                                                       self._rows.data_ptr(), self._n[2], out.data_ptr(), 1 if training else 0,
                                                       torch.cuda.current_stream().cuda_stream), "spectral_sigma_batched")
             for c, (o_s, o_u, Cout, o_v, K) in zip(self.convs, self._views):
-                c._sn_queue.append((out[o_s:o_s + 1], out[o_u:o_u + Cout], out[o_v:o_v + K]))
+                c._sn_queue.append((out[o_s:o_s + 1], out[o_u:o_u + Cout], out[o_v:o_v + K], (self, gen)))
 
 
 def sn_convs(*modules):

@@ -4,6 +4,10 @@ Every operator here launches hand-written HIP kernels on torch's current stream 
 torch supplies device memory, streams and the autograd tape only.  There is no CPU path: tensors
 must be CUDA(HIP) float32.  Activations are NHWC.
 """
+import collections
+import ctypes
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -98,6 +102,105 @@ def _folded(wp, Cout, Cin, KH):
 
 
 # --------------------------------------------------------------------------------------------
+# deferred, batched weight-gradient finish
+# --------------------------------------------------------------------------------------------
+class _WgradJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("bias_src", ctypes.c_void_p), ("w", ctypes.c_void_p), ("sigma", ctypes.c_void_p),
+                ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("tmp", ctypes.c_void_p), ("partial", ctypes.c_void_p),
+                ("grad_w", ctypes.c_void_p), ("grad_b", ctypes.c_void_p),
+                ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32), ("K", ctypes.c_int32), ("fold", ctypes.c_int32),
+                ("n_chunks", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class WgradQueue:
+    """Weight gradients whose destination is the optimizer's flat gradient bucket are not finished one conv at a time
+    (zero a slab, reduce it, un-fold it, spectral-norm chain rule, add: ~5 tiny launches per conv, ~900 per step).
+    ConvFn.backward accumulates the raw gradient into a slot of a pre-zeroed arena and records a job; when the backward
+    pass ends (autograd final callback) ALL jobs are finished by two launches (gim_wgrad_finish_batched) and the arena is
+    cleared by one memset.  `.grad` is complete when backward() returns, exactly as before."""
+    CHUNK = 4096
+    PAGE = 32 << 20  # floats
+
+    def __init__(self):
+        self.pages = []       # [tensor, used]
+        self.jobs = []        # tuples of ints (the job table signature)
+        self.keep = []        # tensors that must outlive the flush
+        self.streams = set()
+        self.cb_queued = False
+        self.cache = collections.OrderedDict()   # job-table signature -> device tables (G / D backward, buffer parities)
+        self.enabled = os.environ.get("GIM_WGRAD_IMMEDIATE") is None
+
+    def take(self, n, device):
+        """n zeroed floats (64-float aligned) that stay valid until the flush."""
+        n = (n + 63) & ~63
+        if not self.pages or self.pages[-1][1] + n > self.pages[-1][0].numel():
+            self.pages.append([torch.zeros(max(n, self.PAGE), device=device, dtype=torch.float32), 0])
+        pg = self.pages[-1]
+        ptr = pg[0].data_ptr() + 4 * pg[1]
+        pg[1] += n
+        return ptr
+
+    def add(self, job, keep):
+        self.jobs.append(job)
+        self.keep.append(keep)
+        self.streams.add(torch.cuda.current_stream())
+        if not self.cb_queued:
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            self.cb_queued = True
+
+    def flush(self):
+        self.cb_queued = False
+        if not self.jobs:
+            return
+        cur = torch.cuda.current_stream()
+        for st in self.streams:   # slots were written on the encoders' side streams too
+            if st != cur:
+                cur.wait_stream(st)
+        device = self.pages[0][0].device
+        sig = tuple(self.jobs)
+        dev_tabs = self.cache.get(sig)
+        if dev_tabs is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("WgradQueue: this backward pass has a job table not seen before; run eager warm-up steps "
+                                   "(at least 2) before capturing a hipGraph")
+            arr = (_WgradJob * len(sig))()
+            tab, tab_sn = [], []
+            for j, jb in enumerate(sig):
+                a = arr[j]
+                (a.src, a.bias_src, a.w, a.sigma, a.u, a.v, a.tmp, a.partial, a.grad_w, a.grad_b,
+                 a.Cout, a.Cin, a.K, a.fold, a.n_chunks) = jb
+                blocks = [(j, c) for c in range(jb[14])]
+                tab += blocks
+                if jb[3]:
+                    tab_sn += blocks
+            host_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
+            host_tab = torch.tensor(tab, dtype=torch.int32).pin_memory()
+            host_sn = torch.tensor(tab_sn if tab_sn else [(0, 0)], dtype=torch.int32).pin_memory()
+            dev_tabs = (host_jobs.to(device, non_blocking=True), host_tab.to(device, non_blocking=True),
+                        host_sn.to(device, non_blocking=True), len(tab), len(tab_sn), (host_jobs, host_tab, host_sn))
+            self.cache[sig] = dev_tabs
+            while len(self.cache) > 16:
+                self.cache.popitem(last=False)
+        else:
+            self.cache.move_to_end(sig)
+        dj, dt, dsn, nb, nbs, _ = dev_tabs
+        check(_lib.load().gim_wgrad_finish_batched(dj.data_ptr(), len(sig), dt.data_ptr(), nb, dsn.data_ptr(), nbs, _stream()),
+              "wgrad_finish_batched")
+        if len(self.pages) > 1:  # first backward of a new shape: merge into one page for the next pass
+            total = sum(pg[1] for pg in self.pages)
+            self.pages = [[torch.zeros(total + (total >> 3), device=device, dtype=torch.float32), 0]]
+            self.cache.clear()
+        else:
+            pg = self.pages[0]
+            pg[0][:pg[1]].zero_()
+            pg[1] = 0
+        self.jobs, self.keep, self.streams = [], [], set()
+
+
+wgrad_queue = WgradQueue()
+
+
+# --------------------------------------------------------------------------------------------
 # convolution / linear
 # --------------------------------------------------------------------------------------------
 class ConvFn(Function):
@@ -108,7 +211,7 @@ class ConvFn(Function):
     res_ups: the residual is stored at half the output resolution."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf=None):
+    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf=None, guard=None):
         lib = _lib.load()
         x = _req(x, "x")
         wp = weight_phys(_req_w(w))
@@ -133,6 +236,7 @@ class ConvFn(Function):
         check(lib.gim_conv2d_fwd(_p(x), _p(wk), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd")
         ctx.save_for_backward(x, w, sigma, u_s, v_s, wf if fold else None, bias)
         ctx.cfg = (N, H, W, Cin, Cout, KH, ups, pre_slope, bias is not None, res is not None, bool(pool), fold, bool(res_ups))
+        ctx.guard = guard
         return y
 
     @staticmethod
@@ -141,11 +245,14 @@ class ConvFn(Function):
         x, w, sigma, u_s, v_s, wf, bias = ctx.saved_tensors
         N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = ctx.cfg
         dy = _req(dy, "dy")
+        if ctx.guard is not None and ctx.guard[0].stale(ctx.guard[1]):
+            raise RuntimeError("the spectral-norm state (sigma, u, v) of this forward pass was overwritten by later forward "
+                               "passes of the same model: run backward before the third forward")
         if _second_order():
             if ups or res_ups:
                 raise NotImplementedError("second-order backward of an upsampling convolution is not on the R1 path")
             dx = ConvDgradFn.apply(dy, w, x, sigma, u_s, v_s, wf, ctx.cfg) if ctx.needs_input_grad[0] else None
-            return dx, None, None, (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None, None, None, None, None
+            return dx, None, None, (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None, None, None, None, None, None
         wp = weight_phys(w)
         sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
         st = _stream()
@@ -168,7 +275,7 @@ class ConvFn(Function):
                 check(lib.gim_upsample2x_bwd(_p(dy), None, 1.0, _p(dres), N, H >> 1, W >> 1, Cout, st), "upsample2x_bwd")
             else:
                 dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st):
@@ -204,6 +311,24 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
     # the finish kernels ADD into it and autograd gets None (no AccumulateGrad add kernel per parameter).
     acc_w = _grad_target(w) if (sigma is not None or not fold) and not torch.is_grad_enabled() else None
     acc_b = _grad_target(bias) if (slab_bias and acc_w is not None) else None
+    if acc_w is not None and wgrad_queue.enabled and not (want_b and slab_bias and acc_b is None):
+        # deferred: raw gradient into an arena slot now, finish of all convs in two launches when backward ends
+        q = wgrad_queue
+        n = Cout * K
+        n_chunks = (n + q.CHUNK - 1) // q.CHUNK
+        src = q.take(Cout * KFF, dev)
+        bsrc = q.take(Cout, dev) if slab_bias else None
+        sn = sigma is not None
+        tmp = q.take(n, dev) if (fold and sn) else None
+        part = q.take(n_chunks, dev) if sn else None
+        check(lib.gim_conv2d_wgrad_acc(_p(dy), _p(x), src, bsrc, sh, st), "conv2d_wgrad_acc")
+        q.add((src, bsrc or 0, _p(wp) if sn else 0, _p(sigma) or 0, _p(u_s) or 0, _p(v_s) or 0, tmp or 0, part or 0,
+               _p(acc_w), _p(acc_b) or 0, Cout, Cin, KH, (2 if ups else 1) if fold else 0, n_chunks), (sigma, u_s, v_s))
+        if want_b and not slab_bias:
+            db = torch.empty(Cout, device=dev, dtype=torch.float32)
+            scr = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
+            check(lib.gim_colsum(_p(dy), _p(db), _p(scr), Mo, Cout, st), "colsum")
+        return None, db
     if want_b and acc_b is None:
         db = torch.empty(Cout, device=dev, dtype=torch.float32)
     if ns == 1 and sigma is None and not fold and acc_w is None:
@@ -283,14 +408,15 @@ def _req_w(w):
     return w
 
 
-def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, wf=None):
-    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf)
+def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, wf=None,
+           guard=None):
+    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard)
 
 
 def linear(x, w, bias=None, pre_slope=1.0):
     """nn.Linear on the last dim (optionally with a fused LeakyReLU on the input)."""
     shp = x.shape
-    y = ConvFn.apply(x.reshape(-1, shp[-1]), w, bias, None, None, None, None, 0, pre_slope, False, False, None)
+    y = ConvFn.apply(x.reshape(-1, shp[-1]), w, bias, None, None, None, None, 0, pre_slope, False, False, None, None)
     return y.view(*shp[:-1], w.shape[0])
 
 

@@ -256,7 +256,7 @@ def test_graphed_step_equals_eager_step():
         if graphed:
             # capture on the first episode's shapes (warm-up steps run on scratch copies of the state)
             state = ({k_: v.clone() for k_, v in au.state_dict().items()}, {k_: v.clone() for k_, v in im.state_dict().items()})
-            gs = GraphedGimStep(trainer, *eps[0], warmup=1)
+            gs = GraphedGimStep(trainer, *eps[0], warmup=3)
             au.load_state_dict(state[0]); im.load_state_dict(state[1])
             for opt in (tr.authenticator_opt, tr.impersonator_opt):
                 opt.flat_m.zero_(); opt.flat_v.zero_(); opt._step_dev.zero_(); opt._host_step = 0
