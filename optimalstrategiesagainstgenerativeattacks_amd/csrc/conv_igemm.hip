@@ -731,10 +731,14 @@ static const bool g_xcd = getenv("GIM_CONV_NO_XCD") == nullptr;  // A/B switch
 static const int g_small_tiles = getenv("GIM_CONV_SMALL_TILES") ? atoi(getenv("GIM_CONV_SMALL_TILES")) : 24;
 static const int g_force_ksplit = getenv("GIM_CONV_KSPLIT") ? atoi(getenv("GIM_CONV_KSPLIT")) : 0;  // experiments
 
-static int plan_ksplit(long long wgs, int nk) {
+// split-K factor: enough workgroups to give every CU several (about 512 of the 128x128 tiles, proportionally more of the
+// smaller ones - measured: profiles/r01_ksplit_sweep.txt, r01_tile_sweep2.txt), never fewer than 8 K-steps per split
+static int plan_ksplit(long long wgs, int nk, int tile_area) {
     if (g_force_ksplit > 0) return g_force_ksplit > nk ? nk : g_force_ksplit;
-    if (wgs >= 448 || nk < 16) return 1;
-    long long ks = (512 + wgs / 2) / wgs;
+    static const int scale_small = getenv("GIM_KS_SCALE") ? atoi(getenv("GIM_KS_SCALE")) : 2;  // experiments
+    const long long target = tile_area >= 128 * 128 ? 512 : 512 * scale_small;
+    if (wgs >= target - target / 8 || nk < 16) return 1;
+    long long ks = (target + wgs / 2) / wgs;
     if (ks > nk / 8) ks = nk / 8;
     if (ks > 6) ks = 6;
     return ks < 1 ? 1 : (int)ks;
@@ -745,7 +749,7 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
     const int ncls = p.g.pc ? 4 : 1;
     const int nk = (p.Ktot + KB - 1) / KB;
-    p.ksplit = plan_ksplit((long long)gx * gy * ncls, nk);
+    p.ksplit = plan_ksplit((long long)gx * gy * ncls, nk, BM * BN);
     p.kper = (nk + p.ksplit - 1) / p.ksplit;
     p.ksplit = (nk + p.kper - 1) / p.kper;
     if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
@@ -771,14 +775,18 @@ static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K
     const int M = p.M, Cb = p.Cb;
     static const int force_tile = getenv("GIM_CONV_TILE") ? atoi(getenv("GIM_CONV_TILE")) : 0;  // experiments
+    static const int big_cfg = getenv("GIM_CONV_BIG") ? atoi(getenv("GIM_CONV_BIG")) : 641;       // experiments
+    static const int mid_cfg = getenv("GIM_CONV_MID") ? atoi(getenv("GIM_CONV_MID")) : 1264;
     if (Cb > 64) {
         const long long t128 = (long long)((M + 127) / 128) * ((Cb + 127) / 128) * (p.g.pc ? 4 : 1);
-        const bool small = force_tile ? force_tile == 64 : t128 < g_small_tiles;
-        if (M <= 64) launch_cfg<64, 128, 1, 2, BMODE, GEN>(p, y_elems, st);
-        else if (small) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
+        int cfg = force_tile ? force_tile : (M <= 64 ? 641 : (t128 < g_small_tiles ? 64 : big_cfg));
+        if (cfg == 641) launch_cfg<64, 128, 1, 2, BMODE, GEN>(p, y_elems, st);
+        else if (cfg == 1264) launch_cfg<128, 64, 2, 1, BMODE, GEN>(p, y_elems, st);
+        else if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
         else launch_cfg<128, 128, 2, 2, BMODE, GEN>(p, y_elems, st);
     } else if (Cb > 32) {
-        if (M <= 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
+        int cfg = M <= 64 ? 64 : mid_cfg;
+        if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
         else launch_cfg<128, 64, 2, 1, BMODE, GEN>(p, y_elems, st);
     } else {
         launch_cfg<128, 32, 1, 1, BMODE, GEN>(p, y_elems, st);

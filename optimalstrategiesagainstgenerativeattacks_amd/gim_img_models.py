@@ -297,13 +297,27 @@ class GIMFaceImpersonator(nn.Module):
         self._sn_plan.run(1, self.training)
         B, m, C, S, _ = leaked_sample.size()
         leaked = ops.to_nhwc(leaked_sample.reshape(B * m, C, S, S))
-        src = ops.mean_dim1(self.src_encoder(leaked).view(B, m, -1))
+        # the source code is first needed by img2img: its encoder (B*m images, far too few workgroups to fill the
+        # chip) runs on a side stream under the env encoder -> noise mapper -> env decoder chain
+        side = None
+        if _TWO_STREAMS and leaked.is_cuda:
+            cur = torch.cuda.current_stream()
+            side = _side_streams(leaked.device)[1]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                src = ops.mean_dim1(self.src_encoder(leaked).view(B, m, -1))
+            leaked.record_stream(side)
+        else:
+            src = ops.mean_dim1(self.src_encoder(leaked).view(B, m, -1))
         env = ops.mean_dim1(self.env_encoder(leaked).view(B, m, -1))
         if z is None:
             z = torch.randn((B, n, self.style_dim), device=leaked_sample.device)
         w = self.env_noise_mapper(z)
         noisy_env = ops.noise_combine(env, w, remove_noise_mean)
         env_img = self.env_decoder(noisy_env.view(B * n, -1))
+        if side is not None:
+            cur.wait_stream(side)
+            src.record_stream(cur)
         first = leaked.view(B, m, S, S, C)[:, 0]
         x = ops.concat2(env_img, first, n)
         style = ops.repeat_dim1(src, n).view(B * n, self.style_dim)
