@@ -18,13 +18,29 @@ from .gim_basic_models import GIMMeanStdFcStat
 
 
 _TWO_STREAMS = os.environ.get("GIM_SINGLE_STREAM") is None  # A/B switch
+_LANE1_SIDE = os.environ.get("GIM_NO_LANE1_SIDE") is None   # A/B switch: side streams inside lane 1 as well (+5 %)
 _STREAMS = {}
 
 
+def _use_side_streams(t):
+    """Lane 1 forks side streams of its own (a fork of a fork).  hipStreamEndCapture of ROCm 7.2 segfaults on that
+    shape of graph (tools/capture_probe.py), so graph capture uses the sequential protocol, lane 0 only (graph.py)."""
+    return _TWO_STREAMS and t.is_cuda and (ops.current_lane() == 0 or _LANE1_SIDE)
+
+
 def _side_streams(device):
-    key = (device.type, device.index)
+    """Two side streams per (device, lane): see ops.lane."""
+    key = (device.type, device.index, ops.current_lane())
     if key not in _STREAMS:
         _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _STREAMS[key]
+
+
+def lane_stream(device, lane):
+    """The main stream of a non-zero lane (lane 0 runs on the caller's current stream)."""
+    key = (device.type, device.index, "lane", lane)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=device)
     return _STREAMS[key]
 
 
@@ -173,7 +189,7 @@ class AdaInImage2Image(nn.Module):
         # the 36 style linears (tiny, latency-bound GEMMs) depend on `style` only: run them all now on a side stream,
         # under the down path, instead of in front of each AdaIN (autograd overlaps their backward the same way)
         svs_res = svs_up = None
-        if _TWO_STREAMS and x.is_cuda:
+        if _use_side_streams(x):
             cur = torch.cuda.current_stream()
             side = _side_streams(x.device)[0]
             side.wait_stream(cur)
@@ -249,7 +265,7 @@ class GIMFaceAuthenticator(nn.Module):
         iteration order - is the reference's (each encoder sees the samples in list order on its own stream).
         autograd replays each backward op on its forward stream, so the backward overlaps the same way."""
         cur = torch.cuda.current_stream()
-        if not _TWO_STREAMS or not samples[0].is_cuda:
+        if not _use_side_streams(samples[0]):
             return ([self.src_encode_sample(s) for s in samples], [self.env_encode_sample(s) for s in samples])
         streams = _side_streams(samples[0].device)
         outs = []
@@ -300,7 +316,7 @@ class GIMFaceImpersonator(nn.Module):
         # the source code is first needed by img2img: its encoder (B*m images, far too few workgroups to fill the
         # chip) runs on a side stream under the env encoder -> noise mapper -> env decoder chain
         side = None
-        if _TWO_STREAMS and leaked.is_cuda:
+        if _use_side_streams(leaked):
             cur = torch.cuda.current_stream()
             side = _side_streams(leaked.device)[1]
             side.wait_stream(cur)

@@ -28,14 +28,14 @@ class GraphedGimStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                gim_step(trainer, *self.static[:3], z=self.static[3])
+                gim_step(trainer, *self.static[:3], z=self.static[3], overlap=False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):
             opt._push_lrs()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = gim_step(trainer, *self.static[:3], z=self.static[3])
+            self.out = gim_step(trainer, *self.static[:3], z=self.static[3], overlap=False)
         # the capture pass itself advanced the host-side counters once without running: undo nothing, but note
         # that parameters were NOT changed by the capture (kernels are only recorded)
         for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):

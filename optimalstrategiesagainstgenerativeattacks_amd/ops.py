@@ -197,7 +197,36 @@ class WgradQueue:
         self.jobs, self.keep, self.streams = [], [], set()
 
 
-wgrad_queue = WgradQueue()
+# Lanes: the generator step's backward and the discriminator step overlap on the GPU (gim_img_training.gim_step);
+# each lane has its own arena / job queue (and its own side streams, gim_img_models._side_streams).
+_LANE = [0]
+_QUEUES = {0: WgradQueue()}
+wgrad_queue = _QUEUES[0]
+
+
+def current_lane():
+    return _LANE[0]
+
+
+def _queue():
+    q = _QUEUES.get(_LANE[0])
+    if q is None:
+        q = _QUEUES[_LANE[0]] = WgradQueue()
+    return q
+
+
+class lane:
+    """Context manager: work issued inside belongs to lane `idx` (host-side selection, read by the autograd worker)."""
+
+    def __init__(self, idx):
+        self.idx = idx
+
+    def __enter__(self):
+        self.prev = _LANE[0]
+        _LANE[0] = self.idx
+
+    def __exit__(self, *exc):
+        _LANE[0] = self.prev
 
 
 # --------------------------------------------------------------------------------------------
@@ -312,8 +341,8 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
     acc_w = _grad_target(w) if (sigma is not None or not fold) and not torch.is_grad_enabled() else None
     acc_b = _grad_target(bias) if (slab_bias and acc_w is not None) else None
     if acc_w is not None and wgrad_queue.enabled and not (want_b and slab_bias and acc_b is None):
+        q = _queue()
         # deferred: raw gradient into an arena slot now, finish of all convs in two launches when backward ends
-        q = wgrad_queue
         n = Cout * K
         n_chunks = (n + q.CHUNK - 1) // q.CHUNK
         src = q.take(Cout * KFF, dev)
