@@ -855,7 +855,7 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
     // about two workgroups per CU in total, and at least 32 K-steps (512 pixels) per workgroup so that the
     // slab write + later slab reduction stay small next to the MFMA work
-    static const int target = getenv("GIM_WGRAD_TARGET") ? atoi(getenv("GIM_WGRAD_TARGET")) : 512;
+    static const int target = getenv("GIM_WGRAD_TARGET") ? atoi(getenv("GIM_WGRAD_TARGET")) : 1024;
     long long S = (target + tiles - 1) / tiles;
     const long long maxS = (M + 511) / 512;
     if (S > maxS) S = maxS;
