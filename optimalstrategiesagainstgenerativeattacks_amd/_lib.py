@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgim_hip.so")
+LIB_PATH = os.environ.get("GIM_LIB_PATH") or os.path.join(_HERE, "csrc", "libgim_hip.so")  # override: timing experiments
 
 
 class GimConvShape(ctypes.Structure):

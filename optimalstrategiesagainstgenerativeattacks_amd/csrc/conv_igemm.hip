@@ -80,6 +80,7 @@ struct ConvP {
     int Cin_w;
     int M;
     int Ktot;
+    const float* zero;  // 16 bytes of zeros (out-of-range lanes load from here)
     float pre_slope, mask_slope, out_scale;
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
@@ -100,6 +101,21 @@ struct ConvP {
 // per K step only a wave-uniform (tap, channel) offset advances - incrementally, no integer divisions - and the
 // per-row work is two adds, two compares and the load.  Loaded values are not touched until store_tiles (any
 // consumer would pull an s_waitcnt vmcnt(0) in front of the MFMA block).
+// Out-of-range lanes (zero padding, ragged tile edges) load from this zero page instead of being masked off: the
+// main loop then has no exec-mask branches around its global loads (one basic block, loads issue back to back).
+// (Passed to the kernels as a pointer argument so that the select stays a GLOBAL load; a direct reference to the symbol
+// turns the loads into flat loads, which also count against lgkmcnt and stall the LDS reads.)
+__device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+
+static const float* zero_page() {
+    static const float* z = [] {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_zero4)) != hipSuccess) ptr = nullptr;
+        return (const float*)ptr;
+    }();
+    return z;
+}
+
 template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB>
 __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
@@ -146,7 +162,6 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     const int arow = t / QPR, aq = (t % QPR) * 4;
     const int He = g.Hin << g.ups, We = g.Win << g.ups;  // extent of the (virtually upsampled) gathered image
     const int KF2 = g.KF * g.KF;
-    const bool act = p.pre_slope != 1.0f;
 
     // per-row constants of the A gather: pixel origin (for the bounds test) and element offset without the tap
     int a_oy[A_ROWS], a_ox[A_ROWS];
@@ -198,23 +213,16 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
             for (int i = 0; i < A_ROWS; ++i) {
                 const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
                 const bool v = a_ok[i] && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (v) {
-                    const float* src = g.ups ? p.x + a_off[i] + (long long)((iy >> 1) * g.Win + (ix >> 1)) * p.Ca + c0
-                                             : xa + a_off[i];
-                    val = *reinterpret_cast<const f32x4*>(src);
-                }
-                ra[i] = val;
+                const float* src = g.ups ? p.x + a_off[i] + (long long)((iy >> 1) * g.Win + (ix >> 1)) * p.Ca + c0
+                                         : xa + a_off[i];
+                ra[i] = *reinterpret_cast<const f32x4*>(v ? src : p.zero);
             }
             // ---- B: weights ----
             if constexpr (BMODE == 0) {
                 const float* wb = p.w + ((long long)wtap * p.Cin_w + c0);
 #pragma unroll
-                for (int i = 0; i < B_ROWS; ++i) {
-                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (b_ok0[i]) val = *reinterpret_cast<const f32x4*>(wb + b_off0[i]);
-                    rb0[i] = val;
-                }
+                for (int i = 0; i < B_ROWS; ++i)
+                    rb0[i] = *reinterpret_cast<const f32x4*>(b_ok0[i] ? wb + b_off0[i] : p.zero);
             } else {
                 const float* wb = p.w + (((long long)c0 * KF2 + wtap) * p.Cin_w + n0);
                 if constexpr (BSCALAR) {
@@ -228,13 +236,14 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
 #pragma unroll
                     for (int i = 0; i < B_PER4; ++i) {
                         const int krow = b4_krow + i * B_RSTEP;
-                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                        if (krow < KB && b4_cok) val = *reinterpret_cast<const f32x4*>(wb + (long long)krow * KF2 * p.Cin_w + b4_col);
-                        rb4[i] = val;
+                        rb4[i] = *reinterpret_cast<const f32x4*>((krow < KB && b4_cok) ? wb + (long long)krow * KF2 * p.Cin_w + b4_col : p.zero);
                     }
                 }
             }
             // advance the uniform K position by one step (Ca % KB == 0 on this path)
+#ifdef GIM_DBG_SAMEADDR
+            if (k0 < 0)
+#endif
             k_c0 += KB;
             if (k_c0 == p.Ca) {
                 k_c0 = 0;
@@ -316,12 +325,12 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            f32x4 val = ra[i];
-            if (act) {  // fused leaky-relu (0 < slope < 1: max(x, slope*x)), after the loads landed; wave-uniform branch
+            // fused leaky-relu max(x, slope*x) (slope 1 = identity), IN PLACE and branch-free: a conditional copy of the
+            // staged registers gets hoisted above the MFMA block and drags the s_waitcnt vmcnt(0) with it
+            // (tools/isa_waitcnt_check.py), which exposes the global-load latency every K-step
 #pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], val[e] * p.pre_slope);
-            }
-            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = val;
+            for (int e = 0; e < 4; ++e) ra[i][e] = fmaxf(ra[i][e], ra[i][e] * p.pre_slope);
+            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
         }
         if constexpr (BMODE == 0) {
 #pragma unroll
@@ -363,12 +372,23 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     __syncthreads();
     for (int ks = ks0; ks < nk; ++ks) {
         const int buf = ks & 1;
+#ifndef GIM_DBG_NOLOAD   // timing experiments only (tools/micro/build_dbg.sh): results are wrong with any GIM_DBG_* flag
         if (ks + 1 < nk) load_tiles((ks + 1) * KB);
+#endif
+#ifndef GIM_NO_IGEMM_FENCE
+        __builtin_amdgcn_sched_barrier(0);  // nothing that touches the staged registers may move into the MFMA block
+#endif
         const float* Ab = As + buf * A_SZ;
         const float* Bb = Bs + buf * B_SZ;
 #pragma unroll
         for (int kk = 0; kk < KB / 8; ++kk) {
             f32x4 a[TM], b[TN];
+#ifdef GIM_DBG_NOLDS
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ra[i % A_ROWS] + (float)kk;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = ra[(j + 1) % A_ROWS] - (float)kk;
+#else
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + 32 * i + r) * LDK + 8 * kk + 4 * h]);
 #pragma unroll
@@ -380,6 +400,7 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
                     for (int e = 0; e < 4; ++e) b[j][e] = Bb[(8 * kk + 4 * h + e) * BN + wn0 + 32 * j + r];
                 }
             }
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -388,8 +409,15 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
+#ifndef GIM_NO_IGEMM_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef GIM_DBG_NOSTORE
         if (ks + 1 < nk) store_tiles(buf ^ 1);
+#endif
+#ifndef GIM_DBG_NOBARRIER
         __syncthreads();
+#endif
     }
 
     // ---- epilogue: out_scale/sigma, bias, residual, activation mask; logical pixel -> stored pixel ----
@@ -440,6 +468,7 @@ struct WgP {
     int mper;
     float pre_slope;   // leaky-relu on the gathered x operand
     float a_slope;     // leaky-relu on the dy operand (role-swapped use: sub-pixel conv wgrad)
+    const float* zero; // 16 bytes of zeros (out-of-range lanes load from here)
     int atomic;        // 1: all pixel slices add into ONE pre-zeroed slab with float atomics (no reduce pass)
 };
 
@@ -488,8 +517,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
             const int m = mb + row;
             const bool v = a_cok && row < BK && m < mend;
             if constexpr (VEC == 4) {
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (v) val = *reinterpret_cast<const f32x4*>(p.dy + (long long)m * p.Cout + co0 + ac);
+                const f32x4 val = *reinterpret_cast<const f32x4*>(v ? p.dy + (long long)m * p.Cout + co0 + ac : p.zero);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ra[i][e] = val[e];
             } else {
@@ -508,8 +536,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
             const bool v = b_jok && row < BK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
             const long long off = ((long long)(n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci;
             if constexpr (VEC == 4) {
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (v) val = *reinterpret_cast<const f32x4*>(p.x + off);
+                const f32x4 val = *reinterpret_cast<const f32x4*>(v ? p.x + off : p.zero);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rb[i][e] = val[e];
             } else {
@@ -578,6 +605,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nk) load_tiles(mbeg + (ks + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);  // keep every consumer of the staged registers behind the MFMA block
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             float a[TM], b[TN];
@@ -591,6 +619,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
                 for (int jj = 0; jj < TN; ++jj)
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (ks + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
@@ -799,6 +828,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     if (rc) return rc;
     GIM_CHECK_ARG(x && w && y, "conv fwd: null pointer");
     ConvP p{};
+    p.zero = zero_page();
     const bool up_fold = s->ups && s->wfold;
     p.g = s->pool ? geo_s2(s, false) : (up_fold ? geo_pc(s, 0) : geo_plain(s, false));
     p.x = x; p.w = w; p.bias = bias; p.sigma = sigma; p.res = residual; p.mask_x = nullptr; p.y = y;
@@ -820,6 +850,7 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(mask_x && s->ups && !up_fold), "conv dgrad: mask_x with ups == 1 needs folded weights");
     ConvP p{};
+    p.zero = zero_page();
     // pool: dx [N,H,W,Cin] from dy [N,H/2,W/2,Cout] by input-parity classes; sub-pixel (ups+wfold): dx
     // [N,H/2,W/2,Cin] directly from dy [N,H,W,Cout] by a stride-2 gather; plain: dx at the conv's resolution
     p.g = s->pool ? geo_pc(s, 1) : (up_fold ? geo_s2(s, true) : geo_plain(s, true));
@@ -900,6 +931,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(up_fold && bias_slabs), "conv wgrad: the sub-pixel form does not produce the bias gradient (use gim_colsum)");
     WgP p{};
+    p.zero = zero_page();
     if (s->pool) p.g = geo_s2(s, false);
     else if (up_fold) p.g = geo_s2(s, false);
     else p.g = geo_plain(s, false);
