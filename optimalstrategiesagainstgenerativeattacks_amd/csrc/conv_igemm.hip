@@ -81,6 +81,7 @@ struct ConvP {
     int M;
     int Ktot;
     const float* zero;  // 16 bytes of zeros (out-of-range lanes load from here)
+    unsigned x_bytes;   // size of the gathered tensor (buffer-resource range of the fast path)
     float pre_slope, mask_slope, out_scale;
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
@@ -114,6 +115,15 @@ static const float* zero_page() {
         return (const float*)ptr;
     }();
     return z;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define BUF_OOB 0x80000000u   // byte offset beyond any num_records: the buffer load returns 0 for that lane
+// 16-byte load through a raw buffer resource: address = base + voff (per lane) + soff (wave-uniform, SGPR); lanes whose
+// voff is outside [0, num_records) read zeros.  The per-K-step address work is ONE scalar add: ordinary VALU instructions
+// are not free next to MFMA (tools/micro/mfma_valu.hip: each one takes ~4 cycles from the matrix pipe).
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
 template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB>
@@ -189,6 +199,49 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     const int b4_krow = t / B_U, b4_col = (t % B_U) * 4;
     const bool b4_cok = (n0 + b4_col) < p.Cb;  // Cb % 4 == 0 on the vector path: the whole quad is in range
 
+    // ---- fast path (!GEN): buffer loads, per-lane byte offsets fixed per tap, wave-uniform K-step offsets in SGPRs ----
+    // Rows beyond the ragged tile edge (m >= M, output channel >= Cb) are clamped to a valid row instead of zeroed: their
+    // results are never stored.  Only the spatial zero padding needs zeros (BUF_OOB).
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xFFFFFFFFu, 0x00020000);
+    unsigned a_base[A_ROWS], a_cur[A_ROWS];
+    unsigned b_voff[BMODE == 0 ? B_ROWS : B_PER4];
+    if constexpr (!GEN) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int m = min(m0 + arow + RP * i, p.M - 1);
+            const int n = m >> (g.logH + g.logW);
+            a_oy[i] = ((m >> g.logW) & (g.H - 1)) * g.s_in + g.off_y;
+            a_ox[i] = (m & (g.W - 1)) * g.s_in + g.off_x;
+            a_base[i] = (unsigned)((n * g.Hin * g.Win * p.Ca + aq) * 4);
+            a_cur[i] = BUF_OOB;
+        }
+        if constexpr (BMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) {
+                const int row = min(n0 + min(arow + RP * i, BN - 1), p.Cb - 1);
+                b_voff[i] = (unsigned)((row * KF2 * p.Cin_w + aq) * 4);
+            }
+        } else if constexpr (!BSCALAR) {
+#pragma unroll
+            for (int i = 0; i < B_PER4; ++i) {
+                const int krow = min(b4_krow + i * B_RSTEP, KB - 1);
+                const int col = min(n0 + b4_col, p.Cb - 4);
+                b_voff[i] = (unsigned)((krow * KF2 * p.Cin_w + col) * 4);
+            }
+        }
+    }
+    // per-tap refresh of the A offsets (runs when the uniform tap changes: every Ca / KB K-steps)
+    auto set_tap = [&](int ta, int tb) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
+            const bool v = (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
+            const int py = g.ups ? (iy >> 1) : iy, px = g.ups ? (ix >> 1) : ix;
+            a_cur[i] = v ? a_base[i] + (unsigned)((py * g.Win + px) * p.Ca * 4) : BUF_OOB;
+        }
+    };
+
     f32x4 ra[A_ROWS];
     f32x4 rb0[B_ROWS];
     float rb1[B_PER];
@@ -201,31 +254,25 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
         k_c0 = k0 - tap * p.Ca;
         k_ta = tap / g.Tw;
         k_tb = tap - k_ta * g.Tw;
+        set_tap(k_ta, k_tb);
     };
 
     auto load_tiles = [&](int k0) {
         if constexpr (!GEN) {
             const int ta = k_ta, tb = k_tb, c0 = k_c0;
             const int wtap = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
-            // ---- A: gathered activations ----
-            const float* xa = p.x + ((long long)(ta * g.Win + tb) * p.Ca + c0);  // uniform part (ups == 0)
+            // ---- A: gathered activations (offsets of this tap are in a_cur; the channel offset is wave-uniform) ----
+            const unsigned sa = (unsigned)(c0 * 4);
 #pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
-                const bool v = a_ok[i] && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
-                const float* src = g.ups ? p.x + a_off[i] + (long long)((iy >> 1) * g.Win + (ix >> 1)) * p.Ca + c0
-                                         : xa + a_off[i];
-                ra[i] = *reinterpret_cast<const f32x4*>(v ? src : p.zero);
-            }
+            for (int i = 0; i < A_ROWS; ++i) ra[i] = buf_load4(rx, a_cur[i], sa);
             // ---- B: weights ----
             if constexpr (BMODE == 0) {
-                const float* wb = p.w + ((long long)wtap * p.Cin_w + c0);
+                const unsigned sb = (unsigned)((wtap * p.Cin_w + c0) * 4);
 #pragma unroll
-                for (int i = 0; i < B_ROWS; ++i)
-                    rb0[i] = *reinterpret_cast<const f32x4*>(b_ok0[i] ? wb + b_off0[i] : p.zero);
+                for (int i = 0; i < B_ROWS; ++i) rb0[i] = buf_load4(rw, b_voff[i], sb);
             } else {
-                const float* wb = p.w + (((long long)c0 * KF2 + wtap) * p.Cin_w + n0);
                 if constexpr (BSCALAR) {
+                    const float* wb = p.w + (((long long)c0 * KF2 + wtap) * p.Cin_w + n0);
 #pragma unroll
                     for (int i = 0; i < B_PER; ++i) {
                         const int idx = t + 256 * i;
@@ -233,11 +280,9 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
                         rb1[i] = (n0 + col) < p.Cb ? wb[(long long)krow * KF2 * p.Cin_w + col] : 0.f;
                     }
                 } else {
+                    const unsigned sb = (unsigned)(((c0 * KF2 + wtap) * p.Cin_w) * 4);
 #pragma unroll
-                    for (int i = 0; i < B_PER4; ++i) {
-                        const int krow = b4_krow + i * B_RSTEP;
-                        rb4[i] = *reinterpret_cast<const f32x4*>((krow < KB && b4_cok) ? wb + (long long)krow * KF2 * p.Cin_w + b4_col : p.zero);
-                    }
+                    for (int i = 0; i < B_PER4; ++i) rb4[i] = buf_load4(rw, b_voff[i], sb);
                 }
             }
             // advance the uniform K position by one step (Ca % KB == 0 on this path)
@@ -248,6 +293,7 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
             if (k_c0 == p.Ca) {
                 k_c0 = 0;
                 if (++k_tb == g.Tw) { k_tb = 0; ++k_ta; }
+                set_tap(k_ta, k_tb);
             }
         } else {
             // ---- generic K: per-element (tap, channel) decode; small layers only (Cin in {1,2,3,6}, Cout = 3) ----
@@ -834,6 +880,11 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     p.x = x; p.w = w; p.bias = bias; p.sigma = sigma; p.res = residual; p.mask_x = nullptr; p.y = y;
     p.Ca = s->Cin; p.Cb = s->Cout; p.Cin_w = s->Cin;
     p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cin;
+    {
+        const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.Ca * 4ull;
+        GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv: gathered tensor larger than 2 GiB (32-bit buffer offsets): split the batch");
+        p.x_bytes = (unsigned)xb;
+    }
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
@@ -857,6 +908,11 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
     p.x = dy; p.w = w; p.bias = nullptr; p.sigma = sigma; p.res = nullptr; p.mask_x = mask_x; p.y = dx;
     p.Ca = s->Cout; p.Cb = s->Cin; p.Cin_w = s->Cin;
     p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cout;
+    {
+        const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.Ca * 4ull;
+        GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv: gathered tensor larger than 2 GiB (32-bit buffer offsets): split the batch");
+        p.x_bytes = (unsigned)xb;
+    }
     p.pre_slope = 1.f; p.mask_slope = s->pre_slope; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = 0;
     const size_t y_elems = (size_t)s->N * (s->H >> (up_fold ? 1 : 0)) * (s->W >> (up_fold ? 1 : 0)) * s->Cin;
     const bool gen = (s->Cout % BK) != 0 || ((uintptr_t)dy & 15);
