@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 #define BK 16  // wgrad pixel step; also the K granularity the fast paths require (channels % 16 == 0)
 
@@ -82,6 +83,7 @@ struct ConvP {
     int Ktot;
     const float* zero;  // 16 bytes of zeros (out-of-range lanes load from here)
     unsigned x_bytes;   // size of the gathered tensor (buffer-resource range of the fast path)
+    float pos_inf;      // +infinity as a run-time value
     float pre_slope, mask_slope, out_scale;
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
             // staged registers gets hoisted above the MFMA block and drags the s_waitcnt vmcnt(0) with it
             // (tools/isa_waitcnt_check.py), which exposes the global-load latency every K-step
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ra[i][e] = fmaxf(ra[i][e], ra[i][e] * p.pre_slope);
+            for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.pre_slope, p.pos_inf);  // med3(x, s*x, +inf) = max(x, s*x) in 2 VALU (a literal inf folds back into the 3-op canonicalising max)
             *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
         }
         if constexpr (BMODE == 0) {
@@ -414,10 +416,10 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     const int nk = min(nk_all, ks0 + p.kper);
     if constexpr (!GEN) seek(ks0 * KB);
     load_tiles(ks0 * KB);
-    store_tiles(ks0 & 1);
+    store_tiles(0);
     __syncthreads();
-    for (int ks = ks0; ks < nk; ++ks) {
-        const int buf = ks & 1;
+    auto kstep = [&](int ks, auto BUFC) {
+        constexpr int buf = decltype(BUFC)::value;   // compile-time LDS buffer: offsets fold into the ds_read / ds_write immediates
 #ifndef GIM_DBG_NOLOAD   // timing experiments only (tools/micro/build_dbg.sh): results are wrong with any GIM_DBG_* flag
         if (ks + 1 < nk) load_tiles((ks + 1) * KB);
 #endif
@@ -464,6 +466,10 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
 #ifndef GIM_DBG_NOBARRIER
         __syncthreads();
 #endif
+    };
+    for (int ks = ks0; ks < nk; ks += 2) {
+        kstep(ks, std::integral_constant<int, 0>());
+        if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>());
     }
 
     // ---- epilogue: out_scale/sigma, bias, residual, activation mask; logical pixel -> stored pixel ----
@@ -875,6 +881,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     GIM_CHECK_ARG(x && w && y, "conv fwd: null pointer");
     ConvP p{};
     p.zero = zero_page();
+    p.pos_inf = __builtin_inff();
     const bool up_fold = s->ups && s->wfold;
     p.g = s->pool ? geo_s2(s, false) : (up_fold ? geo_pc(s, 0) : geo_plain(s, false));
     p.x = x; p.w = w; p.bias = bias; p.sigma = sigma; p.res = residual; p.mask_x = nullptr; p.y = y;
@@ -902,6 +909,7 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
     GIM_CHECK_ARG(!(mask_x && s->ups && !up_fold), "conv dgrad: mask_x with ups == 1 needs folded weights");
     ConvP p{};
     p.zero = zero_page();
+    p.pos_inf = __builtin_inff();
     // pool: dx [N,H,W,Cin] from dy [N,H/2,W/2,Cout] by input-parity classes; sub-pixel (ups+wfold): dx
     // [N,H/2,W/2,Cin] directly from dy [N,H,W,Cout] by a stride-2 gather; plain: dx at the conv's resolution
     p.g = s->pool ? geo_pc(s, 1) : (up_fold ? geo_s2(s, true) : geo_plain(s, true));
