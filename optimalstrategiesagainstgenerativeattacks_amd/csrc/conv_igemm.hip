@@ -521,6 +521,8 @@ struct WgP {
     float pre_slope;   // leaky-relu on the gathered x operand
     float a_slope;     // leaky-relu on the dy operand (role-swapped use: sub-pixel conv wgrad)
     const float* zero; // 16 bytes of zeros (out-of-range lanes load from here)
+    unsigned x_bytes;  // size of the gathered tensor x (buffer-resource range)
+    float pos_inf;     // +infinity as a run-time value (keeps med3(x, s*x, inf) from folding back into a 3-op max)
     int atomic;        // 1: all pixel slices add into ONE pre-zeroed slab with float atomics (no reduce pass)
 };
 
@@ -528,7 +530,7 @@ struct WgP {
 // bases); VEC = 1: scalar fallback (3- and 6-channel image layers, 1-channel Omniglot).
 // Workgroups of the first column tile also produce the bias gradient sum_m dY[m][co] of their pixel slice from
 // the dY values they stream anyway (bias_slabs[slice][Cout]).
-template <int BM, int BN, int TM, int TN, int VEC>
+template <int BM, int BN, int TM, int TN, int VEC, bool FASTB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
@@ -557,61 +559,117 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     const int dh = ta + g.off_y, dw = tb + g.off_x;
     const bool do_bias = p.bias_slabs != nullptr && blockIdx.x == 0;
 
+    // ---- VEC == 4 fast addressing (tools/micro/mfma_valu.hip: VALU work is paid in matrix-pipe time) ----
+    // A (dy rows): buffer resource whose BASE advances by BK rows per step and whose num_records shrinks to the rows left
+    //   in this pixel slice: lane offsets are constants and rows beyond the slice read zeros - no per-step VALU at all.
+    // B (gathered x): when one K step never crosses an image row (W % BK == 0, no on-the-fly upsample) the element offset
+    //   is  U(n, oy, ox0)  [wave-uniform, SALU]  +  L(tap, channel, tile row)  [lane constant]; only the zero-padding test
+    //   is per lane (two adds, two compares, one select per tile row).  Otherwise the generic per-row address path runs.
+    constexpr bool fastb = FASTB;  // host: VEC == 4 && ups == 0 && W % BK == 0
+    unsigned a_v[A_PER], b_l[B_PER];
+    int b_dx[B_PER];
+    // the most negative lane constant is shifted into the base pointer so that every offset is a non-negative 32-bit value
+    const int b_bias = ((g.off_y < 0 ? -g.off_y : 0) * g.Win + (g.off_x < 0 ? -g.off_x : 0)) * p.Cin * 4;
+    const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - b_bias), 0, p.x_bytes + (unsigned)b_bias, 0x00020000);
+    if constexpr (VEC == 4) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int row = ak + i * A_RSTEP;
+            a_v[i] = row < BK ? (unsigned)((row * p.Cout + min(co0 + ac, p.Cout - 4)) * 4) : BUF_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int row = bk + i * B_RSTEP;
+            b_dx[i] = row * g.s_in + dw;
+            b_l[i] = (b_jok && row < BK) ? (unsigned)(((dh * g.Win + b_dx[i]) * p.Cin + ci) * 4 + b_bias) : BUF_OOB;
+        }
+    }
+
     float ra[A_PER][VEC], rb[B_PER][VEC];
     float bsum[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) bsum[e] = 0.f;
 
     auto load_tiles = [&](int mb) {
+        if constexpr (VEC == 4) {
+            const int left = mend - mb;  // > 0
+            const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(p.dy + (long long)mb * p.Cout), 0, (unsigned)min(left, BK) * (unsigned)p.Cout * 4u, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int row = ak + i * A_RSTEP;
-            const int m = mb + row;
-            const bool v = a_cok && row < BK && m < mend;
-            if constexpr (VEC == 4) {
-                const f32x4 val = *reinterpret_cast<const f32x4*>(v ? p.dy + (long long)m * p.Cout + co0 + ac : p.zero);
+            for (int i = 0; i < A_PER; ++i) {
+                const f32x4 val = buf_load4(ra_rs, a_v[i], 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ra[i][e] = val[e];
-            } else {
-                float val = 0.f;
-                if (v) val = p.dy[(long long)m * p.Cout + co0 + ac];
-                ra[i][0] = val;
             }
-        }
+            if constexpr (fastb) {
+                const int n = mb >> (g.logH + g.logW);
+                const int oys = ((mb >> g.logW) & (g.H - 1)) * g.s_in, oxs = (mb & (g.W - 1)) * g.s_in;
+                const unsigned u = (unsigned)((((n * g.Hin + oys) * g.Win) + oxs) * p.Cin * 4);
+                const bool vy = (unsigned)(oys + dh) < (unsigned)He;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int row = bk + i * B_RSTEP;
-            const int m = mb + row;
-            const int n = m >> (g.logH + g.logW);
-            const int iy = ((m >> g.logW) & (g.H - 1)) * g.s_in + dh;
-            const int ix = (m & (g.W - 1)) * g.s_in + dw;
-            const bool v = b_jok && row < BK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
-            const long long off = ((long long)(n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci;
-            if constexpr (VEC == 4) {
-                const f32x4 val = *reinterpret_cast<const f32x4*>(v ? p.x + off : p.zero);
+                for (int i = 0; i < B_PER; ++i) {
+                    const bool v = vy && (unsigned)(oxs + b_dx[i]) < (unsigned)We;
+                    const f32x4 val = buf_load4(rxb, v ? b_l[i] : BUF_OOB, u);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[i][e] = val[e];
+                    for (int e = 0; e < 4; ++e) rb[i][e] = val[e];
+                }
             } else {
-                float val = 0.f;
-                if (v) val = p.x[off];
-                rb[i][0] = val;
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) {
+                    const int row = bk + i * B_RSTEP;
+                    const int m = mb + row;
+                    const int n = m >> (g.logH + g.logW);
+                    const int iy = ((m >> g.logW) & (g.H - 1)) * g.s_in + dh;
+                    const int ix = (m & (g.W - 1)) * g.s_in + dw;
+                    const bool v = b_jok && row < BK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
+                    const unsigned off = (unsigned)((((n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci) * 4 + b_bias);
+                    const f32x4 val = buf_load4(rxb, v ? off : BUF_OOB, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[i][e] = val[e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int row = ak + i * A_RSTEP;
+                const int m = mb + row;
+                const bool v = a_cok && row < BK && m < mend;
+                ra[i][0] = v ? p.dy[(long long)m * p.Cout + co0 + ac] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int row = bk + i * B_RSTEP;
+                const int m = mb + row;
+                const int n = m >> (g.logH + g.logW);
+                const int iy = ((m >> g.logW) & (g.H - 1)) * g.s_in + dh;
+                const int ix = (m & (g.W - 1)) * g.s_in + dw;
+                const bool v = b_jok && row < BK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
+                const long long off = ((long long)(n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci;
+                rb[i][0] = v ? p.x[off] : 0.f;
             }
         }
     };
     // activations and the bias sums consume the loaded values here, after the MFMA block, never in load_tiles
+    const bool act_a = p.a_slope != 1.0f, act_b = p.pre_slope != 1.0f;  // block-uniform
     auto store_tiles = [&](int buf) {
+        if (act_a) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
+            for (int i = 0; i < A_PER; ++i)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                ra[i][e] = lrelu_f(ra[i][e], p.a_slope);
-                if (do_bias) bsum[e] += ra[i][e];
-            }
+                for (int e = 0; e < VEC; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.a_slope, p.pos_inf);
         }
+        if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i)
+            for (int i = 0; i < A_PER; ++i)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) rb[i][e] = lrelu_f(rb[i][e], p.pre_slope);
+                for (int e = 0; e < VEC; ++e) bsum[e] += ra[i][e];
+        }
+        if (act_b) {
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) rb[i][e] = __builtin_amdgcn_fmed3f(rb[i][e], rb[i][e] * p.pre_slope, p.pos_inf);
+        }
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int row = ak + i * A_RSTEP;
@@ -973,13 +1031,13 @@ extern "C" int gim_conv2d_wgrad_slabs(const gim_conv_shape* s) {
     return g_wgrad_atomic ? 1 : wgrad_plan(s).ns;
 }
 
-template <int VEC>
+template <int VEC, bool FASTB>
 static void launch_wgrad(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, VEC>), g, dim3(256), 0, st, p);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, VEC>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, VEC>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, VEC>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, VEC>), g, dim3(256), 0, st, p);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, VEC, FASTB>), g, dim3(256), 0, st, p);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, VEC, FASTB>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, VEC, FASTB>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, VEC, FASTB>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, VEC, FASTB>), g, dim3(256), 0, st, p);
 }
 
 // prezeroed: the caller guarantees slabs / bias_slabs hold zeros (or a partial sum to add to): pixel slices are combined
@@ -996,6 +1054,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     GIM_CHECK_ARG(!(up_fold && bias_slabs), "conv wgrad: the sub-pixel form does not produce the bias gradient (use gim_colsum)");
     WgP p{};
     p.zero = zero_page();
+    p.pos_inf = __builtin_inff();
     if (s->pool) p.g = geo_s2(s, false);
     else if (up_fold) p.g = geo_s2(s, false);
     else p.g = geo_plain(s, false);
@@ -1006,14 +1065,21 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     }
     p.slabs = slabs; p.bias_slabs = bias_slabs;
     p.M = q.M; p.Kcols = q.cols; p.mper = q.mper; p.atomic = atomic ? 1 : 0;
+    {
+        const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.Cin * 4ull;
+        GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv wgrad: gathered tensor larger than 2 GiB (32-bit buffer offsets): split the batch");
+        p.x_bytes = (unsigned)xb;
+    }
     if (atomic && !prezeroed) {
         (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
         if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
     }
     dim3 g((q.cols + q.bn - 1) / q.bn, (q.rows + q.bm - 1) / q.bm, q.ns);
     const bool vec = (s->Cin % 4 == 0) && (s->Cout % 4 == 0) && !(((uintptr_t)dy | (uintptr_t)x) & 15);
-    if (vec) launch_wgrad<4>(p, q.bm, q.bn, g, (hipStream_t)stream);
-    else launch_wgrad<1>(p, q.bm, q.bn, g, (hipStream_t)stream);
+    const bool fastb = vec && p.g.ups == 0 && (p.g.W & (BK - 1)) == 0;
+    if (fastb) launch_wgrad<4, true>(p, q.bm, q.bn, g, (hipStream_t)stream);
+    else if (vec) launch_wgrad<4, false>(p, q.bm, q.bn, g, (hipStream_t)stream);
+    else launch_wgrad<1, false>(p, q.bm, q.bn, g, (hipStream_t)stream);
     return gim_check_launch("gim_conv2d_wgrad");
 }
 
