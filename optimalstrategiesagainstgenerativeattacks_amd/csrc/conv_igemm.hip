@@ -475,6 +475,39 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     // ---- epilogue: out_scale/sigma, bias, residual, activation mask; logical pixel -> stored pixel ----
     const float scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
     const bool first = kslice == 0;
+    if (g.os == 1 && !p.res_ups) {  // block-uniform
+        // The stored pixel is the logical one: element (m, co) lives at (m * Cb + co) * 4.  Buffer stores with ONE 32-bit lane
+        // offset per accumulator block and the row step (k * Cb * 4) as the wave-uniform SGPR offset: a single FMA of VALU
+        // work per element (64-bit index arithmetic per element cost more matrix-pipe time than the K loop's address work);
+        // rows m >= M fall outside num_records and are dropped by the range check.
+        const unsigned ybytes = (unsigned)p.M * (unsigned)p.Cb * 4u;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (p.res && first) ? ybytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_x, 0, p.mask_x ? ybytes : 0u, 0x00020000);
+        const unsigned rowb = (unsigned)p.Cb * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int co = n0 + wn0 + 32 * j + r;
+                const bool cok = co < p.Cb;
+                const float bv = (p.bias && first && cok) ? p.bias[co] : 0.f;
+                const unsigned voff = cok ? (unsigned)(((m0 + wm0 + 32 * i + 4 * h) * p.Cb + co) * 4) : BUF_OOB;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned soff = (unsigned)((e & 3) + 8 * (e >> 2)) * rowb;  // wave-uniform
+                    float v = acc[i][j][e] * scale + bv;
+                    if (p.res && first) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, voff, soff, 0));
+                    if (p.mask_x) {
+                        const float xm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, voff, soff, 0));
+                        v *= (xm > 0.f ? 1.0f : p.mask_slope);
+                    }
+                    if (p.ksplit > 1) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, ry, voff, soff, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, soff, 0);
+                }
+            }
+        return;
+    }
     const int Ho = g.H * g.os, Wo = g.W * g.os;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -487,15 +520,11 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m >= p.M) continue;
-                long long o = (long long)m * p.Cb + co;  // os == 1: the logical pixel index is the stored one
-                long long ro = o;
-                if (g.os != 1 || p.res_ups) {  // wave-uniform
-                    const int n = m >> (g.logH + g.logW);
-                    const int oy = ((m >> g.logW) & (g.H - 1)) * g.os + g.py;
-                    const int ox = (m & (g.W - 1)) * g.os + g.px;
-                    o = (((long long)n * Ho + oy) * Wo + ox) * p.Cb + co;
-                    ro = p.res_ups ? (((long long)n * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * p.Cb + co : o;
-                }
+                const int n = m >> (g.logH + g.logW);
+                const int oy = ((m >> g.logW) & (g.H - 1)) * g.os + g.py;
+                const int ox = (m & (g.W - 1)) * g.os + g.px;
+                const long long o = (((long long)n * Ho + oy) * Wo + ox) * p.Cb + co;
+                const long long ro = p.res_ups ? (((long long)n * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * p.Cb + co : o;
                 float v = acc[i][j][e] * scale + bv;
                 if (p.res && first) v += p.res[ro];
                 if (p.mask_x) v *= (p.mask_x[o] > 0.f ? 1.0f : p.mask_slope);
@@ -952,6 +981,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     }
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
+    GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: output larger than 2 GiB (32-bit buffer offsets): split the batch");
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
     if (gen) launch_igemm<0, 1>(p, y_elems, (hipStream_t)stream);
     else launch_igemm<0, 0>(p, y_elems, (hipStream_t)stream);
@@ -981,6 +1011,7 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
     }
     p.pre_slope = 1.f; p.mask_slope = s->pre_slope; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = 0;
     const size_t y_elems = (size_t)s->N * (s->H >> (up_fold ? 1 : 0)) * (s->W >> (up_fold ? 1 : 0)) * s->Cin;
+    GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: output larger than 2 GiB (32-bit buffer offsets): split the batch");
     const bool gen = (s->Cout % BK) != 0 || ((uintptr_t)dy & 15);
     const bool bscalar = (s->Cin % 4) != 0 || ((uintptr_t)w & 15);
     hipStream_t st = (hipStream_t)stream;
