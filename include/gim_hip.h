@@ -227,6 +227,12 @@ int gim_lrelu_mask_mul(const float* g, const float* x, float slope, float* out, 
 int gim_sqsum_rows_fwd(const float* x, float* out, int B, int64_t L, void* stream);
 int gim_sqsum_rows_bwd(const float* x, const float* dout, float* dx, int B, int64_t L, void* stream);
 
+/* Input pipeline: gather episodes from a resident uint8 NHWC image bank into float NCHW samples in [-1, 1] with an optional
+ * horizontal flip per image - load_image / process_pil_image / RandomHorizontalFlip of data_handling/img_datasets.py:296-303,43-46
+ * after the (offline) resize.  out[i] = (bank[idx[i]] / 255) * 2 - 1. */
+int gim_episode_gather(const uint8_t* bank, const int32_t* idx, const uint8_t* flip, float* out, int n_out, int H, int W, int C,
+                       void* stream);
+
 /* ImgAttention mix (models/model_blocks.py:598-608; only with use_img_att): per pixel (P pixels, C channels, NHWC)
  * s1 = sum_c q1*k1, s2 = sum_c q2*k2, (a1, a2) = softmax(s1, s2), out = x1*a1 + v2*a2; att [P] keeps a1. */
 int gim_img_att_mix_fwd(const float* q1, const float* k1, const float* q2, const float* k2, const float* x1, const float* v2,

@@ -10,12 +10,15 @@ from .gim_img_models import (AdaInImage2Image, Encoder, EnvDecoder, GIMFaceAuthe
                              GIMFaceImpersonator, get_au, get_im)
 from .gim_gaussian_trainer import GIMGaussianTrainer
 from .gim_img_trainer import GIMImgTrainer
-from .gim_img_training import au_eval_step, au_train_step, gim_step, im_eval_step, im_train_step
+from .data import EpisodeBank, synthetic_bank
+from .gim_img_training import (au_eval_step, au_train_step, eval_step, gim_step, im_eval_step, im_train_step, train_epoch,
+                               train_gim_imgs)
+from .training_logger import Logger
 from .optim import FusedAdam
 from .training_utils import CheckpointIO, DataParallelMock, EpisodeParallel, GlobalStep, adjust_batch_size
 
 __all__ = [
     "get_au", "get_im", "Encoder", "EnvDecoder", "AdaInImage2Image", "GIMFaceDis", "GIMFaceAuthenticator",
     "GIMFaceImpersonator", "GIMImgTrainer", "GIMGaussianTrainer", "im_train_step", "au_train_step", "im_eval_step", "au_eval_step",
-    "gim_step", "FusedAdam", "DataParallelMock", "EpisodeParallel", "GlobalStep", "CheckpointIO", "adjust_batch_size",
+    "gim_step", "train_epoch", "eval_step", "train_gim_imgs", "EpisodeBank", "synthetic_bank", "Logger", "FusedAdam", "DataParallelMock", "EpisodeParallel", "GlobalStep", "CheckpointIO", "adjust_batch_size",
 ]

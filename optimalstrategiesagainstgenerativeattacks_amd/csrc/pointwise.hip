@@ -668,3 +668,30 @@ extern "C" int gim_lrelu_mask_mul(const float* g, const float* x, float slope, f
     hipLaunchKernelGGL(lrelu_mask_mul_kernel, dim3(pw_blocks((long long)n)), dim3(256), 0, (hipStream_t)stream, g, x, out, (long long)n, slope);
     return gim_check_launch("gim_lrelu_mask_mul");
 }
+
+// ---------------------------------------------------------------- input pipeline
+// Episode batching on the GPU (data_handling/img_datasets.py:68-103,296-303 restated for a resident image bank):
+// out[i][c][y][x] = (bank[idx[i]][y][flip[i] ? W-1-x : x][c] / 255) * 2 - 1     (ToTensor, dynamic range (0,1) -> (-1,1),
+// RandomHorizontalFlip decided by the caller).  bank is uint8 NHWC [n_img][H][W][C]; out is float NCHW [n_out][C][H][W].
+__global__ __launch_bounds__(256) void episode_gather_kernel(const uint8_t* __restrict__ bank, const int32_t* __restrict__ idx,
+                                                             const uint8_t* __restrict__ flip, float* __restrict__ out, int H, int W,
+                                                             int C, long long n_total) {
+    const long long hw = (long long)H * W, chw = hw * C;
+    GRID_STRIDE(o, n_total) {
+        const long long i = o / chw;
+        long long r = o - i * chw;
+        const int c = (int)(r / hw);
+        r -= (long long)c * hw;
+        const int y = (int)(r / W), x = (int)(r - (long long)y * W);
+        const int xs = flip[i] ? W - 1 - x : x;
+        const float u = (float)bank[(((long long)idx[i] * H + y) * W + xs) * C + c];
+        out[o] = (u / 255.0f) * 2.0f + (-1.0f);
+    }
+}
+extern "C" int gim_episode_gather(const uint8_t* bank, const int32_t* idx, const uint8_t* flip, float* out, int n_out, int H, int W,
+                                  int C, void* stream) {
+    GIM_CHECK_ARG(bank && idx && flip && out && n_out > 0 && H > 0 && W > 0 && C > 0, "episode_gather: bad args");
+    const long long n = (long long)n_out * H * W * C;
+    hipLaunchKernelGGL(episode_gather_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, bank, idx, flip, out, H, W, C, n);
+    return gim_check_launch("gim_episode_gather");
+}

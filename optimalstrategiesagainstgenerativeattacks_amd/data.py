@@ -1,0 +1,106 @@
+"""GPU-resident episode pipeline: the sample contract of the reference's ``ImgGIMDataSet``
+(data_handling/img_datasets.py:23-110: ``{"real_sample": [n,C,S,S], "leaked_sample": [m,C,S,S], "si_sample": [k,C,S,S],
+"class", "class_name"}`` in [-1, 1], m+n+k DISTINCT images of one class, independent random horizontal flips) served from
+a uint8 image bank that lives in HBM, so that the engine (hundreds of episodes per second) is not starved by JPEG
+decoding and host-side collation.  The bank holds the images already resized to S x S (the reference resizes with PIL at
+load time, img_datasets.py:298); conversion to float, the (0,1) -> (-1,1) range map and the flip run in one HIP kernel
+(``gim_episode_gather``).  288 GB of HBM hold 24 M images of 64x64x3.
+
+Index sampling stays on the host (a few dozen integers per episode); ``EpisodeBank`` is also a ``torch.utils.data.Dataset``
+with the reference's per-index semantics (``index // example_cnt_per_class`` = class), so the reference's DataLoader-based
+loop works on it unchanged.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class EpisodeBank(torch.utils.data.Dataset):
+    def __init__(self, images_u8, class_offsets, m, n, k, example_cnt_per_class=1, mirror=True, class_names=None, seed=0):
+        """images_u8: uint8 [n_img, S, S, C] (NHWC) on the GPU, images of one class contiguous;
+        class_offsets: [n_classes + 1] start offsets into images_u8."""
+        if not (images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.is_contiguous()):
+            raise RuntimeError("EpisodeBank: images must be a contiguous CUDA uint8 [n_img, S, S, C] tensor (no CPU path)")
+        self.bank = images_u8
+        self.offsets = np.asarray(class_offsets, dtype=np.int64)
+        self.m, self.n, self.k = m, n, k
+        self.t = m + n + k
+        sizes = np.diff(self.offsets)
+        keep = sizes >= self.t   # "Filtering classes with less then n+m+k images" (img_datasets.py:59-61)
+        self.class_ids = np.nonzero(keep)[0]
+        self.n_classes = int(keep.sum())
+        self.example_cnt_per_class = example_cnt_per_class
+        self.mirror = mirror
+        self.class_names = class_names
+        self.rng = np.random.default_rng(seed)
+        self.S, self.C = images_u8.shape[1], images_u8.shape[3]
+
+    def __len__(self):
+        return self.n_classes * self.example_cnt_per_class
+
+    # ---- index sampling (host) ----
+    def _draw(self, cls_rows):
+        """[B, t] image indices (distinct within a row) and [B, t] flip flags for the given class rows."""
+        B = len(cls_rows)
+        idx = np.empty((B, self.t), dtype=np.int32)
+        for b, c in enumerate(cls_rows):
+            lo, hi = self.offsets[self.class_ids[c]], self.offsets[self.class_ids[c] + 1]
+            idx[b] = lo + self.rng.choice(hi - lo, size=self.t, replace=False)   # random.sample (img_datasets.py:79)
+        flip = (self.rng.random((B, self.t)) < 0.5) if self.mirror else np.zeros((B, self.t), dtype=bool)
+        return idx, flip.astype(np.uint8)
+
+    def gather(self, idx, flip):
+        """float [len(idx), C, S, S] in [-1, 1] from flat image indices / flip flags (numpy or tensors)."""
+        dev = self.bank.device
+        idx_t = torch.as_tensor(np.ascontiguousarray(idx).reshape(-1), dtype=torch.int32).to(dev, non_blocking=True)
+        flip_t = torch.as_tensor(np.ascontiguousarray(flip).reshape(-1), dtype=torch.uint8).to(dev, non_blocking=True)
+        n_out = idx_t.numel()
+        out = torch.empty((n_out, self.C, self.S, self.S), device=dev, dtype=torch.float32)
+        check(_lib.load().gim_episode_gather(self.bank.data_ptr(), idx_t.data_ptr(), flip_t.data_ptr(), out.data_ptr(), n_out,
+                                             self.S, self.S, self.C, torch.cuda.current_stream().cuda_stream), "episode_gather")
+        return out
+
+    def batch(self, cls_rows):
+        """One collated batch (dict of device tensors, the DataLoader's output format) for the given class rows."""
+        idx, flip = self._draw(cls_rows)
+        B = len(cls_rows)
+        x = self.gather(idx, flip).view(B, self.t, self.C, self.S, self.S)
+        m, n = self.m, self.n
+        out = {"leaked_sample": x[:, :m], "real_sample": x[:, m:m + n], "si_sample": x[:, m + n:],
+               "class": torch.as_tensor(np.asarray(cls_rows, dtype=np.int64))}
+        if self.class_names is not None:
+            out["class_name"] = [self.class_names[self.class_ids[c]] for c in cls_rows]
+        return out
+
+    def __getitem__(self, index):
+        """The reference's per-example contract (one episode, no batch dimension)."""
+        c = index // self.example_cnt_per_class
+        b = self.batch([c])
+        ex = {"real_sample": b["real_sample"][0], "leaked_sample": b["leaked_sample"][0], "si_sample": b["si_sample"][0], "class": c}
+        ex["class_name"] = self.class_names[self.class_ids[c]] if self.class_names is not None else str(int(self.class_ids[c]))
+        return ex
+
+    def gpu_batches(self, batch_size, shuffle, drop_last=True, rank=0, world=1):
+        """Iterator over collated device batches: what ``DataLoader(ds, batch_size, shuffle, drop_last)`` yields, without
+        the host round trip; with world > 1 each rank takes its own slice of every global batch (episodes are the
+        data-parallel unit)."""
+        order = np.arange(len(self))
+        if shuffle:
+            self.rng.shuffle(order)
+        n_full = len(order) // batch_size if drop_last else -(-len(order) // batch_size)
+        per = batch_size // world
+        for i in range(n_full):
+            rows = order[i * batch_size:(i + 1) * batch_size] // self.example_cnt_per_class
+            yield self.batch(list(rows[rank * per:(rank + 1) * per]))
+
+    def num_batches(self, batch_size, drop_last=True):
+        return len(self) // batch_size if drop_last else -(-len(self) // batch_size)
+
+
+def synthetic_bank(n_classes, imgs_per_class, S, C, device, seed=0):
+    """Random uint8 image bank (benchmarks / tests)."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randint(0, 256, (n_classes * imgs_per_class, S, S, C), generator=g, dtype=torch.uint8).to(device)
+    return imgs, np.arange(n_classes + 1) * imgs_per_class

@@ -241,8 +241,10 @@ class GimInstanceNorm2d(nn.Module):
 
 
 def custom_std(x):
-    """models/model_blocks.py:41-48 for x [B, t, D] (standalone helper; the head uses the fused HeadCatFn)."""
-    raise NotImplementedError("custom_std is fused into ops.head_cat on the hot path")
+    """models/model_blocks.py:41-48 for x [B, t, D] -> [B, D] (standalone form for the training loop's encoding
+    statistics; the authenticator head uses the fused HeadCatFn)."""
+    D = x.shape[-1]
+    return ops.mean_std_cat(x)[:, D:]
 
 
 class ResBlockDown(nn.Module):

@@ -83,6 +83,21 @@ class EpisodeParallel(DataParallelMock):
                 dist.broadcast(t.data, src=0)
 
 
+def get_device(device_type, device_ids, verbose=True):
+    """training/utils.py:48-60.  One process drives ONE GPU here: under torch.distributed the device is this rank's
+    (LOCAL_RANK), otherwise the smallest id of device_ids.  There is no CPU path: 'cpu' is refused."""
+    if device_type != 'cuda' or not torch.cuda.is_available():
+        raise RuntimeError("the GIM engine runs on an MI355X only (device_type='cuda'); there is no CPU path")
+    if dist.is_initialized():
+        idx = int(os.environ.get("LOCAL_RANK", "0"))
+    else:
+        idx = min(device_ids) if device_ids else 0
+    if verbose:
+        print('Using device cuda:{}'.format(idx))
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
+
+
 def adjust_batch_size(ds_length, curr_batch_size, n_devices):
     batch_size = min(curr_batch_size, ds_length)
     batch_size = int(n_devices * math.floor(batch_size / n_devices))

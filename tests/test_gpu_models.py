@@ -1,6 +1,7 @@
 """GPU parity, block / network / trainer level: the product modules (HIP path through the C ABI) against the
 golden vectors captured from the reference (tests/golden, fp64) and against the oracle on the same seeded
 inputs.  north_star tolerance: 1e-3 relative on losses / logits (stated per assert)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -403,3 +404,105 @@ def test_overlapped_step_equals_sequential_protocol():
         if err > 3 * noise + 5e-3:
             bad.append((k_, err, noise))
     assert not bad, bad[:5]
+
+
+def test_episode_bank_gather_matches_numpy_restatement():
+    """gim_episode_gather vs a numpy restatement of load_image / ToTensor / adjust_dynamic_range / RandomHorizontalFlip
+    (data_handling/img_datasets.py:43-46,270-303): bit-exact; the sample contract of ImgGIMDataSet.__getitem__ (:68-103)."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    S, C, ncls, per = 8, 3, 5, 9
+    imgs, offs = G.synthetic_bank(ncls, per, S, C, dev(), seed=3)
+    bank = G.EpisodeBank(imgs, offs, m=1, n=3, k=4, example_cnt_per_class=2, mirror=True, seed=11)
+    assert len(bank) == ncls * 2 and bank.n_classes == ncls
+    idx = np.array([0, 7, 13, 44, 20], dtype=np.int32)
+    flip = np.array([0, 1, 0, 1, 1], dtype=np.uint8)
+    got = bank.gather(idx, flip).cpu().numpy()
+    src = imgs.cpu().numpy().astype(np.float32)
+    for i, (a, f) in enumerate(zip(idx, flip)):
+        ref = src[a][:, ::-1] if f else src[a]                       # flip along W (NHWC)
+        ref = (ref / np.float32(255.0)) * np.float32(2.0) + np.float32(-1.0)
+        assert np.array_equal(got[i], ref.transpose(2, 0, 1)), i
+    ex = bank[3]                                                       # index // example_cnt_per_class = class 1
+    assert ex["class"] == 1 and ex["real_sample"].shape == (3, C, S, S) and ex["leaked_sample"].shape == (1, C, S, S)
+    assert ex["si_sample"].shape == (4, C, S, S) and float(ex["si_sample"].abs().max()) <= 1.0
+    b = bank.batch([0, 4, 4])
+    # distinct images within an episode, all from the episode's class
+    i2, _ = bank._draw([2, 2, 0])
+    for row, c in zip(i2, [2, 2, 0]):
+        assert len(set(row.tolist())) == bank.t and all(offs[c] <= v < offs[c + 1] for v in row)
+    assert b["real_sample"].shape == (3, 3, C, S, S) and b["class"].tolist() == [0, 4, 4]
+    # a class with fewer than m+n+k images is filtered out
+    small = G.EpisodeBank(imgs, np.array([0, 3, 45]), m=1, n=3, k=4)
+    assert small.n_classes == 1
+
+
+def test_training_loop_end_to_end_on_synthetic_bank(tmp_path):
+    """train_gim_imgs (training/gim_img_training.py:356-441) for two tiny epochs from a GPU-resident bank: global step,
+    checkpoints, logged scalars, image dumps; the logged losses equal a hand-rolled loop of gim_step on the same batches."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    import tempfile
+    S, C, D, m, n, k = 16, 1, 32, 1, 3, 4
+
+    def make():
+        torch.manual_seed(5)
+        au, im = G.get_au(S, C, D), G.get_im(S, C, D)
+        imgs, offs = G.synthetic_bank(6, 10, S, C, dev(), seed=1)
+        tr_ds = G.EpisodeBank(imgs, offs, m, n, k, example_cnt_per_class=2, mirror=True, seed=21)
+        va_ds = G.EpisodeBank(imgs, offs, m, n, k, example_cnt_per_class=1, mirror=False, seed=22)
+        return au, im, tr_ds, va_ds
+    au, im, tr_ds, va_ds = make()
+    out = str(tmp_path / "run")
+    torch.manual_seed(77)
+    trainer, logger = G.train_gim_imgs(
+        device_name='cuda', device_ids=[0], outdir=out, train_ds=tr_ds, val_ds=va_ds, authenticator=au, impersonator=im,
+        m=m, n=n, k=k, reg_param=0.0, remove_noise_mean=True, au_lr=1e-4, im_lr=1e-4, beta1=0.0, beta2=0.99,
+        env_noise_mapping_lr=1e-6, lr_gamma=0.3, milestones=(), resume_from_ckpt=None, n_epochs=2, batch_size=4, num_workers=0,
+        save_every=4, eval_every=4, save_imgs_every=4, train_eval_indices=[0], val_eval_indices=[1], n_au_steps=1)
+    assert trainer.module.global_step == 2 * (12 // 4) - 1
+    ck = sorted(os.listdir(os.path.join(out, "ckpts")))
+    assert ck == ["model_00000000.pt", "model_00000004.pt"], ck
+    assert [s_ for s_, _ in logger.stats["train_losses"]["dis_loss"]] == [0]        # tb_log_every = 100: only step 0
+    assert [s_ for s_, _ in logger.stats["eval losses"]["gen loss"]] == [0, 4]
+    assert os.path.isdir(os.path.join(out, "imgs", "train_imgs_0000", "impersonator"))
+    # hand-rolled reference of the first iteration: same seeds -> same first batch, same z
+    au2, im2, tr2, _ = make()
+    with tempfile.TemporaryDirectory() as td:
+        tr_ = G.GIMImgTrainer(td, m, n, k, au2.to(dev()), im2.to(dev()), 1e-4, 1e-4, 1e-6, reg_param=0.0)
+    t2 = G.DataParallelMock(tr_)
+    torch.manual_seed(77)
+    batch = next(iter(tr2.gpu_batches(4, True)))
+    tr_.do_global_step()
+    gi, di = G.gim_step(t2, batch["leaked_sample"], batch["real_sample"], batch["si_sample"])
+    # default-initialised generator = rounding-noise amplifier (SURVEY F7): split-K float atomics make two runs differ by ~1e-4
+    assert relerr(di[0], logger.stats["train_losses"]["dis_loss"][0][1]) < 2e-3
+    assert relerr(gi[0], logger.stats["train losses"]["gen loss"][0][1]) < 2e-3
+    # resume: the checkpoint restores parameters, optimizer state and the global step
+    au3, im3, _, _ = make()
+    with tempfile.TemporaryDirectory() as td:
+        tr3 = G.GIMImgTrainer(td, m, n, k, au3.to(dev()), im3.to(dev()), 1e-4, 1e-4, 1e-6, reg_param=0.0)
+    tr3.resume_from_ckpt(os.path.join(out, "ckpts", "model_00000004.pt"))
+    assert tr3.get_global_step() == 4
+
+
+def test_eval_mode_forward_vs_oracle():
+    """Inference path of authentication_eval (eval_gim_on_authentication.py:25-80): both agents in eval mode - no power
+    iteration (u, v unchanged), sigma from the stored vectors - against the oracle with training=False."""
+    tag, cfg = "evalm", "16_1_32"
+    B, m, n, k, c, s, d = 2, 1, 3, 4, 1, 16, 32
+    keys = load_keys(cfg)
+    au_o, im_o = filled_sd(keys["au"], tag + "/au/"), filled_sd(keys["im"], tag + "/im/")
+    au, im = _product_models(tag, cfg)
+    au.eval(); im.eval()
+    leaked, real, si, z = episode(tag, B, m, n, k, c, s, d)
+    before = {k_: v.clone() for k_, v in au.state_dict().items() if k_.endswith(("weight_u", "weight_v"))}
+    with torch.no_grad():
+        fake_o = go.impersonator(im_o, leaked, n, z, False)
+        out_o = go.authenticator(au_o, fake_o, si, False)
+        fake = im(leaked_sample=leaked.float().to(dev()), n=n, remove_noise_mean=True, z=z.float().to(dev()))
+        src = au.src_encode_sample(fake)
+        env = au.env_encode_sample(fake)
+        out = au.dis(test_src=src, test_env=env, si_src=au.src_encode_sample(si.float().to(dev())),
+                     si_env=au.env_encode_sample(si.float().to(dev())))
+    assert relerr(fake, fake_o) < 1e-3 and relerr(out, out_o) < 1e-3
+    for k_, v in before.items():
+        assert torch.equal(v, au.state_dict()[k_]), k_
