@@ -28,6 +28,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 UNIT = {
     "om32": dict(S=32, C=1, E=1.2570, M=0.00210, Dec=0.2274, I2I=5.0189, FC=0.00944, H0=0.01468),
     "vox64": dict(S=64, C=3, E=1.7564, M=0.00210, Dec=0.9583, I2I=6.0770, FC=0.00944, H0=0.01468),
+    # BASELINE config 5 shape (128x128x3, m=5 n=20 k=20), run here in fp32 (the reference has no fp16 path)
+    "vox128": dict(S=128, C=3, E=7.6252, M=0.00210, Dec=3.9013, I2I=23.4687, FC=0.00944, H0=0.01468, mnk=(5, 20, 20), batch=2),
 }
 
 
@@ -165,9 +167,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    m, n, k = 1, 5, 10
     u = UNIT[args.workload]
-    B = args.batch or (16 if args.workload == "vox64" else 32)
+    m, n, k = u.get("mnk", (1, 5, 10))
+    B = args.batch or u.get("batch", 16 if args.workload == "vox64" else 32)
     G, tr = build_trainer(u["S"], u["C"], n, m, k, device, reg_param=args.reg_param)
     trainer = G.EpisodeParallel(tr)
     trainer.broadcast_parameters()

@@ -99,6 +99,9 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
     # generator: backward on the caller's stream (enqueued first: it is the longer dependency chain)
     loss.backward()
     gbwd_done = cur.record_event()
+    # generator's Adam right away: nothing on lane 1 reads the generator's weights, and with several GPUs its gradient
+    # all-reduce (the larger bucket, 246 MB) then runs under the discriminator step instead of after it
+    mod.impersonator_opt.step()
     im = (loss.detach(), fake_d, au_out.detach())
 
     # discriminator step on lane 1
@@ -115,7 +118,6 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
         au = (dloss.detach(), loss_on_real.detach().mean(), loss_on_fake.detach().mean(), reg.detach().mean(),
               out_on_real.detach().mean(), out_on_fake.detach().mean(),
               pred_on_real.detach(), pred_on_fake.detach(), fake_out.detach())
-    mod.impersonator_opt.step()         # generator's Adam: nothing on lane 1 reads the generator's weights
     cur.wait_stream(dstream)
     for t in au:
         t.record_stream(cur)

@@ -172,7 +172,7 @@ def param_names(mod):
 
 def gen_keys():
     out = {}
-    for (s, c, d) in [(16, 1, 32), (32, 1, 512), (64, 3, 512)]:
+    for (s, c, d) in [(16, 1, 32), (32, 1, 512), (64, 3, 512), (128, 3, 512)]:
         au = gim.get_au(s, c, d)
         im = gim.get_im(s, c, d)
         out["%d_%d_%d" % (s, c, d)] = {
@@ -361,6 +361,8 @@ def main():
         gen_nets("om32_f32", 32, 1, 512, 2, 1, 5, 10, torch.float32, full=False)
         gen_nets("vox64_f64", 64, 3, 512, 1, 1, 5, 10, torch.float64, full=False)
         gen_nets("vox64_f32", 64, 3, 512, 1, 1, 5, 10, torch.float32, full=False)
+    if "bench128" in which:   # BASELINE config 5 shape (m > 1 leaked images), fp64
+        gen_nets("vox128_f64", 128, 3, 512, 1, 2, 2, 3, torch.float64, full=False)
 
 
 if __name__ == "__main__":

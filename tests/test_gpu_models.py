@@ -157,6 +157,11 @@ def test_voxceleb_shape_vs_reference_golden():
     _check_nets("vox64_f64", "64_3_512", 1e-3, 5e-2)
 
 
+def test_config5_shape_128_vs_reference_golden():
+    """128x128x3, style_dim 512 (BASELINE config 5 shape, here in fp32), m=2 leaked images, B=1, reference run in fp64."""
+    _check_nets("vox128_f64", "128_3_512", 1e-3, 5e-2)
+
+
 @pytest.mark.parametrize("tag", ["reg0", "reg10", "nau2"])
 def test_trainer_protocol_vs_reference_golden(tag):
     """Real step protocol (im_train_step / im_eval_step + au_train_step, MultiStepLR, FusedAdam) for consecutive

@@ -206,6 +206,11 @@ def test_bench_shape_32_fp64():
     _check_nets("om32_f64", "32_1_512", torch.float64, 1e-8, 1e-6)
 
 
+def test_config5_shape_128_fp64():
+    """128x128x3 (BASELINE config 5 shape), m=2 leaked images, fp64."""
+    _check_nets("vox128_f64", "128_3_512", torch.float64, 1e-8, 1e-6)
+
+
 def test_bench_shape_64_fp32_tolerance():
     """fp32 oracle vs the reference's own fp32 run at the 64x64x3 benchmark shape:
     within the 1e-3 tolerance north_star states for losses/logits."""
