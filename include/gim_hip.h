@@ -112,6 +112,11 @@ typedef struct {
 int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, const int32_t* tab_cols, int n_col_blocks,
                                const int32_t* tab_rows, int n_row_blocks, float* out_base, int training, void* stream);
 
+/* Autotuner hook (tools/conv_autotune.py): force the tile configuration (128 = 128x128, 641 = 64x128, 1264 = 128x64,
+ * 64 = 64x64), the split-K factor and the wgrad slice target of all following conv launches; zeros restore the table /
+ * heuristics.  Process-wide, not thread-safe: for tuning runs only. */
+int gim_conv_tune_override(int tile_cfg, int ksplit, int wgrad_target);
+
 /* Accumulating weight gradient: ADDS the gradient of one convolution (raw, un-finished: dW, dF or G layout as in
  * gim_conv2d_wgrad) into `acc` / `bias_acc` with float atomics and clears nothing - the caller hands in zeroed (or
  * partially accumulated) buffers, typically slots of one arena cleared once per backward pass. */

@@ -83,6 +83,7 @@ struct ConvP {
     int Ktot;
     const float* zero;  // 16 bytes of zeros (out-of-range lanes load from here)
     unsigned x_bytes;   // size of the gathered tensor (buffer-resource range of the fast path)
+    int tune_ks;        // host only: split-K factor from the tuning table (0 = heuristic)
     float pos_inf;      // +infinity as a run-time value
     float pre_slope, mask_slope, out_scale;
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
@@ -897,12 +898,35 @@ static const bool g_xcd = getenv("GIM_CONV_NO_XCD") == nullptr;  // A/B switch
 // below this many 128x128 output tiles a launch uses 64x64 tiles: 4x the workgroups and a 4x shorter MFMA chain per
 // K step (a workgroup cannot finish faster than its serial K loop: 0.85 us per step at 128x128)
 static const int g_small_tiles = getenv("GIM_CONV_SMALL_TILES") ? atoi(getenv("GIM_CONV_SMALL_TILES")) : 24;
-static const int g_force_ksplit = getenv("GIM_CONV_KSPLIT") ? atoi(getenv("GIM_CONV_KSPLIT")) : 0;  // experiments
+static int g_force_ksplit = getenv("GIM_CONV_KSPLIT") ? atoi(getenv("GIM_CONV_KSPLIT")) : 0;  // experiments / autotuner
+static int g_force_tile = getenv("GIM_CONV_TILE") ? atoi(getenv("GIM_CONV_TILE")) : 0;
+static int g_wgrad_target = getenv("GIM_WGRAD_TARGET") ? atoi(getenv("GIM_WGRAD_TARGET")) : 0;   // 0: table / default
+static const bool g_use_table = getenv("GIM_CONV_NO_TABLE") == nullptr;
+
+// Launch configurations measured per layer shape on an MI355X (tools/conv_autotune.py writes conv_tune_table.inc):
+// {kind (0 fwd-style, 1 dgrad-style, 2 wgrad), M, Ca, Cb, Ktot, parity classes, tile config, split-K | wgrad slice target}.
+// Shapes that are not in the table use the heuristics below.
+struct TuneEntry { int kind, M, Ca, Cb, Ktot, pc, tile, ks; };
+static const TuneEntry g_tune[] = {
+#include "conv_tune_table.inc"
+    {-1, 0, 0, 0, 0, 0, 0, 0}};
+static const TuneEntry* tune_lookup(int kind, int M, int Ca, int Cb, int Ktot, int pc) {
+    if (!g_use_table) return nullptr;
+    for (const TuneEntry* e = g_tune; e->kind >= 0; ++e)
+        if (e->kind == kind && e->M == M && e->Ca == Ca && e->Cb == Cb && e->Ktot == Ktot && e->pc == pc) return e;
+    return nullptr;
+}
+
+extern "C" int gim_conv_tune_override(int tile_cfg, int ksplit, int wgrad_target) {
+    g_force_tile = tile_cfg; g_force_ksplit = ksplit; g_wgrad_target = wgrad_target;
+    return 0;
+}
 
 // split-K factor: enough workgroups to give every CU several (about 512 of the 128x128 tiles, proportionally more of the
 // smaller ones - measured: profiles/r01_ksplit_sweep.txt, r01_tile_sweep2.txt), never fewer than 8 K-steps per split
-static int plan_ksplit(long long wgs, int nk, int tile_area) {
+static int plan_ksplit(long long wgs, int nk, int tile_area, int table_ks) {
     if (g_force_ksplit > 0) return g_force_ksplit > nk ? nk : g_force_ksplit;
+    if (table_ks > 0) return table_ks > nk ? nk : table_ks;
     static const int scale_small = getenv("GIM_KS_SCALE") ? atoi(getenv("GIM_KS_SCALE")) : 2;  // experiments
     const long long target = tile_area >= 128 * 128 ? 512 : 512 * scale_small;
     if (wgs >= target - target / 8 || nk < 16) return 1;
@@ -917,7 +941,7 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
     const int ncls = p.g.pc ? 4 : 1;
     const int nk = (p.Ktot + KB - 1) / KB;
-    p.ksplit = plan_ksplit((long long)gx * gy * ncls, nk, BM * BN);
+    p.ksplit = plan_ksplit((long long)gx * gy * ncls, nk, BM * BN, p.tune_ks);
     p.kper = (nk + p.ksplit - 1) / p.ksplit;
     p.ksplit = (nk + p.kper - 1) / p.kper;
     if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
@@ -942,22 +966,27 @@ template <int BMODE, int GEN>
 static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K
     const int M = p.M, Cb = p.Cb;
-    static const int force_tile = getenv("GIM_CONV_TILE") ? atoi(getenv("GIM_CONV_TILE")) : 0;  // experiments
+    const int force_tile = g_force_tile;
+    ConvP pt = p;
+    const TuneEntry* te = (force_tile || g_force_ksplit) ? nullptr : tune_lookup(BMODE, M, p.Ca, Cb, p.Ktot, p.g.pc);
+    pt.tune_ks = te ? te->ks : 0;
+    const int table_tile = te ? te->tile : 0;
     static const int big_cfg = getenv("GIM_CONV_BIG") ? atoi(getenv("GIM_CONV_BIG")) : 641;       // experiments
     static const int mid_cfg = getenv("GIM_CONV_MID") ? atoi(getenv("GIM_CONV_MID")) : 1264;
+    const int want = force_tile ? force_tile : table_tile;   // 0: heuristic
     if (Cb > 64) {
         const long long t128 = (long long)((M + 127) / 128) * ((Cb + 127) / 128) * (p.g.pc ? 4 : 1);
-        int cfg = force_tile ? force_tile : (M <= 64 ? 641 : (t128 < g_small_tiles ? 64 : big_cfg));
-        if (cfg == 641) launch_cfg<64, 128, 1, 2, BMODE, GEN>(p, y_elems, st);
-        else if (cfg == 1264) launch_cfg<128, 64, 2, 1, BMODE, GEN>(p, y_elems, st);
-        else if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
-        else launch_cfg<128, 128, 2, 2, BMODE, GEN>(p, y_elems, st);
+        int cfg = want ? want : (M <= 64 ? 641 : (t128 < g_small_tiles ? 64 : big_cfg));
+        if (cfg == 641) launch_cfg<64, 128, 1, 2, BMODE, GEN>(pt, y_elems, st);
+        else if (cfg == 1264) launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st);
+        else if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st);
+        else launch_cfg<128, 128, 2, 2, BMODE, GEN>(pt, y_elems, st);
     } else if (Cb > 32) {
-        int cfg = M <= 64 ? 64 : mid_cfg;
-        if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st);
-        else launch_cfg<128, 64, 2, 1, BMODE, GEN>(p, y_elems, st);
+        int cfg = (want == 64 || want == 1264) ? want : (M <= 64 ? 64 : mid_cfg);
+        if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st);
+        else launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st);
     } else {
-        launch_cfg<128, 32, 1, 1, BMODE, GEN>(p, y_elems, st);
+        launch_cfg<128, 32, 1, 1, BMODE, GEN>(pt, y_elems, st);
     }
 }
 
@@ -1039,7 +1068,11 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
     // about two workgroups per CU in total, and at least 32 K-steps (512 pixels) per workgroup so that the
     // slab write + later slab reduction stay small next to the MFMA work
-    static const int target = getenv("GIM_WGRAD_TARGET") ? atoi(getenv("GIM_WGRAD_TARGET")) : 1024;
+    int target = g_wgrad_target;
+    if (!target) {
+        const TuneEntry* te = tune_lookup(2, (int)M, q.rows, q.cols, s->KH, (s->pool ? 1 : 0) + (up_fold ? 2 : 0));
+        target = te ? te->ks : 1024;
+    }
     long long S = (target + tiles - 1) / tiles;
     const long long maxS = (M + 511) / 512;
     if (S > maxS) S = maxS;
