@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--workload", default="vox64")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--write", action="store_true")
+    ap.add_argument("--append", action="store_true", help="keep the entries already in the table (other workloads)")
     ap.add_argument("--min-gain", type=float, default=0.03)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -134,10 +135,16 @@ def main():
               % (kind, ",".join(str(c) for c in cfg), calls, t_auto, best[0], best[1], best[2], sav))
     if args.write:
         path = os.path.join(ROOT, "optimalstrategiesagainstgenerativeattacks_amd", "csrc", "conv_tune_table.inc")
+        old, seen = "", set()
+        if args.append and os.path.exists(path):
+            old = open(path).read()
+            import re
+            for mm in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), \d+, \d+\}", old):
+                seen.add(tuple(int(v) for v in mm.groups()))
         with open(path, "w") as f:
+            f.write(old)
             f.write("// generated by tools/conv_autotune.py --workload %s --batch %d on an MI355X; entries beat the heuristic by > %d %%\n"
                     % (args.workload, args.batch, int(args.min_gain * 100)))
-            seen = set()
             for kd, M_, Ca_, Cb_, Kt_, pc_, tl, ks, gain, kind, cfg in entries:
                 key = (kd, M_, Ca_, Cb_, Kt_, pc_)
                 if key in seen:
