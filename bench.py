@@ -187,7 +187,7 @@ def main():
         tr.update_learning_rate()
         if graphed is not None:
             return graphed(leaked, real, si, z)
-        return G.gim_step(trainer, leaked, real, si, z=z)
+        return G.gim_step(trainer, leaked, real, si, z=z, defer_join=True)   # joined by the next step / the final synchronize
 
     def fence():
         torch.cuda.synchronize()
@@ -208,6 +208,8 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         out = step()
+    from optimalstrategiesagainstgenerativeattacks_amd import ops as _ops
+    _ops.join_lanes()   # the last discriminator step runs on its own stream: ev1 must come after it
     ev1.record()
     fence()
     dt = time.time() - t0

@@ -91,6 +91,7 @@ class GIMImgTrainer(nn.Module):
         return loss.squeeze()
 
     def authenticator_forward(self, fake_sample, real_sample, si_sample, grad=True):
+        ops.join_lanes()
         if self.reg_param > 0:  # training/gim_img_trainer.py:98-100
             real_sample.requires_grad_()
             si_sample.requires_grad_()
@@ -120,6 +121,7 @@ class GIMImgTrainer(nn.Module):
 
     def impersonator_forward(self, leaked_sample, si_sample, z=None):
         fake_sample = self.impersonator(leaked_sample=leaked_sample, n=self.n, remove_noise_mean=self.remove_noise_mean, z=z)
+        ops.join_lanes()   # a discriminator step still running on lane 1 (gim_step(defer_join=True)) owns the weights read next
         with _frozen(self.authenticator):
             auth_out = self.authenticator(test_sample=fake_sample, si_sample=si_sample)
         loss = self.gan_loss(dis_out=auth_out, target=1.)
@@ -136,6 +138,7 @@ class GIMImgTrainer(nn.Module):
         print('Resuming training from iteration {}'.format(self.get_global_step()))
 
     def save(self, epoch):
+        ops.join_lanes()
         print("\nSaving checkpoint...\n")
         self.checkpoint_io.save(global_step=self.get_global_step(), last_epoch=epoch,
                                 filename="model_{:08}.pt".format(self.get_global_step()))

@@ -63,7 +63,7 @@ def au_train_step(trainer, real_sample, fake_sample, si_sample):
             pred_on_real.detach(), pred_on_fake.detach(), fake_sample.detach())
 
 
-def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=None):
+def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=None, defer_join=False):
     """One training iteration on one episode batch: generator step then discriminator step on the fake
     sample produced with the pre-update generator (training/gim_img_training.py:225-239, n_au_steps=1).
 
@@ -72,6 +72,10 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
     discriminator step runs on its own stream (lane 1) next to the generator's backward, with two orderings kept:
     the discriminator's Adam update waits for the generator's backward (which reads those weights), and the caller's
     stream waits for the discriminator step at the end.  Results are those of the sequential protocol.
+    defer_join=True additionally leaves the caller's stream un-joined at return, so that the generator part of the NEXT
+    iteration's forward runs under the tail of this discriminator step; the join happens where the discriminator's weights
+    or outputs are next needed (ops.join_lanes(): inside the trainer's forward modes, save(), and by callers before they read
+    the returned discriminator statistics).
     overlap=False (or GIM_NO_STEP_OVERLAP=1) runs the two steps back to back; hipGraph capture does (a hipGraph replays
     parallel branches slower than eager streams run them: 234 vs 282 episodes/s)."""
     if overlap is None:
@@ -118,7 +122,10 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
         au = (dloss.detach(), loss_on_real.detach().mean(), loss_on_fake.detach().mean(), reg.detach().mean(),
               out_on_real.detach().mean(), out_on_fake.detach().mean(),
               pred_on_real.detach(), pred_on_fake.detach(), fake_out.detach())
-    cur.wait_stream(dstream)
+    if defer_join:
+        ops.defer_join(dstream)
+    else:
+        cur.wait_stream(dstream)
     for t in au:
         t.record_stream(cur)
     return im, au
@@ -214,7 +221,7 @@ def train_epoch(device, logger, epoch, trainer, train_ds, val_ds, train_batch_si
         global_step = trainer.module.global_step
 
         if (global_step + 1) % n_au_steps == 0:
-            (im_loss, fake_sample, _), au = gim_step(trainer, leaked_sample, real_sample, si_sample)
+            (im_loss, fake_sample, _), au = gim_step(trainer, leaked_sample, real_sample, si_sample, defer_join=True)
         else:
             im_loss, fake_sample, _ = im_eval_step(trainer=trainer, leaked_sample=leaked_sample, si_sample=si_sample)
             au = au_train_step(trainer=trainer, real_sample=real_sample, fake_sample=fake_sample, si_sample=si_sample)
@@ -227,6 +234,7 @@ def train_epoch(device, logger, epoch, trainer, train_ds, val_ds, train_batch_si
         buf["au_pred_on_fake"].append(au_pred_on_fake.view(-1))
 
         if global_step % tb_log_every == 0:
+            ops.join_lanes()
             logger.add_scalar(category='lr', k='au', v=trainer.module.au_lr, global_step=global_step)
             logger.add_scalar(category='lr', k='im', v=trainer.module.im_lr, global_step=global_step)
             logger.add_scalar(category='lr', k='im_lm', v=trainer.module.im_noise_mapping_lr, global_step=global_step)
@@ -246,6 +254,7 @@ def train_epoch(device, logger, epoch, trainer, train_ds, val_ds, train_batch_si
                 buf[k_] = []
 
         if global_step % tb_log_enc_every == 0:
+            ops.join_lanes()
             with torch.no_grad():
                 au = trainer.module.authenticator
                 enc = {}
@@ -267,6 +276,7 @@ def train_epoch(device, logger, epoch, trainer, train_ds, val_ds, train_batch_si
             sample_and_save_imgs(device=device, logger=logger, trainer=trainer, ds=val_ds, ds_prefix='val', indices=val_eval_indices, dbg=dbg)
         if global_step % eval_every == 0:
             eval_step(device=device, trainer=trainer, ds=val_ds, logger=logger, batch_size=val_batch_size)
+    ops.join_lanes()
 
 
 def train_gim_imgs(device_name, device_ids, outdir, train_ds, val_ds, authenticator, impersonator, m, n, k,

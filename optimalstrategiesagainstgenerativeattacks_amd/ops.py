@@ -215,6 +215,23 @@ def _queue():
     return q
 
 
+_PENDING_JOIN = []   # streams of lane-1 work the caller's stream has not waited for yet (gim_step(defer_join=True))
+
+
+def defer_join(stream):
+    _PENDING_JOIN.append(stream)
+
+
+def join_lanes():
+    """Make the current stream wait for lane work whose join was deferred.  Called before anything reads what the
+    discriminator step wrote: its weights (the next generator step's D forward), its outputs, a checkpoint."""
+    if _PENDING_JOIN:
+        cur = torch.cuda.current_stream()
+        for st in _PENDING_JOIN:
+            cur.wait_stream(st)
+        del _PENDING_JOIN[:]
+
+
 class lane:
     """Context manager: work issued inside belongs to lane `idx` (host-side selection, read by the autograd worker)."""
 

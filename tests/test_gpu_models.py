@@ -281,8 +281,9 @@ def test_graphed_step_equals_eager_step():
             # after the first update the two runs differ by the order of the float atomics (Adam with beta1 = 0
             # turns last-bit gradient differences into lr-sized weight differences); logits here are ~1e-3
             assert relerr(b, a, atol=1e-3) < (1e-4 if it == 0 else 2e-2), it
-    worst = max(relerr(sd_g[k_], sd_e[k_]) for k_ in sd_e)
-    assert worst < 5e-3, worst
+    # conv biases in front of a norm layer have zero gradient: Adam(beta1 = 0) random-walks them by +-lr per step
+    bad = [(k_, relerr(sd_g[k_], sd_e[k_])) for k_ in sd_e if relerr(sd_g[k_], sd_e[k_]) > (5.5e-2 if k_.endswith(".bias") else 5e-3)]
+    assert not bad, bad[:5]
 
 
 @pytest.mark.parametrize("tag,reg", [("gauss", 0.0), ("gauss_r1", 1.0)])
@@ -384,31 +385,38 @@ def test_overlapped_step_equals_sequential_protocol():
     eps = [[t.float().to(dev()) for t in episode("%s/%d" % (tag, it), B, m, n, k, c, s, d)] for it in range(3)]
     assert gt._OVERLAP
     runs = []
-    for mode in ("seq", "seq", "overlap"):
+    from optimalstrategiesagainstgenerativeattacks_amd import ops as gops
+    for mode in ("seq", "seq", "overlap", "overlap_defer"):
         au, im = _product_models(tag, cfg)
         with tempfile.TemporaryDirectory() as td:
             tr = G.GIMImgTrainer(td, m, n, k, au, im, 1e-3, 1e-3, 1e-4, reg_param=0.0)
         trainer = G.DataParallelMock(tr)
         outs = []
         for leaked, real, si, z in eps:
-            if mode == "overlap":
-                gi, di = G.gim_step(trainer, leaked, real, si, z=z)
+            if mode.startswith("overlap"):
+                # defer_join: the next iteration's generator forward starts under this discriminator step; the outputs of
+                # the discriminator step are read only after join_lanes() below
+                gi, di = G.gim_step(trainer, leaked, real, si, z=z, defer_join=(mode == "overlap_defer"))
             else:
                 gi = G.im_train_step(trainer, leaked, si, z=z)
                 di = G.au_train_step(trainer, real, gi[1], si)
-            outs.append((gi[0].clone(), gi[2].clone(), di[0].clone(), di[4].clone()))
+            outs.append((gi[0], gi[2], di[0], di[4]))
+        gops.join_lanes()
         torch.cuda.synchronize()
+        outs = [tuple(t.clone() for t in o) for o in outs]
         runs.append((outs, {k_: v.clone() for k_, v in list(au.state_dict().items()) + list(im.state_dict().items())}))
-    for it, (a, b) in enumerate(zip(runs[0][0], runs[2][0])):
-        for x, y in zip(a, b):
-            assert relerr(y, x) < (1e-5 if it == 0 else 2e-2), it
-    bad = []
-    for k_ in runs[0][1]:
-        noise = relerr(runs[1][1][k_], runs[0][1][k_])
-        err = relerr(runs[2][1][k_], runs[0][1][k_])
-        if err > 3 * noise + 5e-3:
-            bad.append((k_, err, noise))
-    assert not bad, bad[:5]
+    for r in (2, 3):
+        for it, (a, b) in enumerate(zip(runs[0][0], runs[r][0])):
+            for x, y in zip(a, b):
+                assert relerr(y, x) < (1e-5 if it == 0 else 2e-2), (r, it)
+        bad = []
+        for k_ in runs[0][1]:
+            noise = relerr(runs[1][1][k_], runs[0][1][k_])
+            err = relerr(runs[r][1][k_], runs[0][1][k_])
+            # conv biases in front of a norm layer: zero gradient, +-lr random walk under Adam(beta1 = 0): up to ~3 % after 3 steps
+            if err > 3 * noise + 5e-3 + (5e-2 if k_.endswith(".bias") else 0.0):
+                bad.append((k_, err, noise))
+        assert not bad, (r, bad[:5])
 
 
 def test_episode_bank_gather_matches_numpy_restatement():
