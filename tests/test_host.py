@@ -213,7 +213,7 @@ def test_logger_mirror_and_training_loop_cadence(tmp_path):
     orig = (gt.gim_step, gt.im_eval_step, gt.au_train_step, gt.au_eval_step)
     orig_std = gt.mb.custom_std
     gt.mb.custom_std = lambda x: x.std(1)
-    gt.gim_step = lambda tr, l, r, s, z=None, overlap=None: (calls.append(("G+D", tr.module.global_step)), ((one, torch.zeros(2), one), au_ret))[1]
+    gt.gim_step = lambda tr, l, r, s, z=None, overlap=None, defer_join=False: (calls.append(("G+D", tr.module.global_step)), ((one, torch.zeros(2), one), au_ret))[1]
     gt.im_eval_step = lambda trainer, leaked_sample, si_sample, z=None: (calls.append(("Geval", trainer.module.global_step)), (one, torch.zeros(2), one))[1]
     gt.au_train_step = lambda trainer, real_sample, fake_sample, si_sample: (calls.append(("D", trainer.module.global_step)), au_ret)[1]
     gt.au_eval_step = lambda trainer, real_sample, fake_sample, si_sample: (calls.append(("Deval", trainer.module.global_step)), au_ret)[1]
