@@ -122,6 +122,7 @@ static const float* zero_page() {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define BUF_OOB 0x80000000u   // byte offset beyond any num_records: the buffer load returns 0 for that lane
+#define BUF_MAX_BYTES 0x7FFFFFF0ull   // largest operand one launch addresses (the launchers halve the batch beyond it)
 // 16-byte load through a raw buffer resource: address = base + voff (per lane) + soff (wave-uniform, SGPR); lanes whose
 // voff is outside [0, num_records) read zeros.  The per-K-step address work is ONE scalar add: ordinary VALU instructions
 // are not free next to MFMA (tools/micro/mfma_valu.hip: each one takes ~4 cycles from the matrix pipe).
@@ -995,6 +996,18 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(x && w && y, "conv fwd: null pointer");
+    {   // operands beyond the 32-bit buffer-offset range: halve the batch (images are independent)
+        const size_t xi = (size_t)(s->H >> s->ups) * (s->W >> s->ups) * s->Cin;        // elements per image
+        const size_t yi = (size_t)(s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
+        const size_t ri = s->res_ups ? yi / 4 : yi;
+        if (s->N > 1 && (xi > yi ? xi : yi) * s->N * sizeof(float) > BUF_MAX_BYTES) {
+            gim_conv_shape a = *s, b = *s;
+            a.N = s->N / 2; b.N = s->N - a.N;
+            rc = gim_conv2d_fwd(x, w, bias, sigma, residual, y, &a, stream);
+            if (rc) return rc;
+            return gim_conv2d_fwd(x + a.N * xi, w, bias, sigma, residual ? residual + a.N * ri : nullptr, y + a.N * yi, &b, stream);
+        }
+    }
     ConvP p{};
     p.zero = zero_page();
     p.pos_inf = __builtin_inff();
@@ -1005,12 +1018,12 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cin;
     {
         const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.Ca * 4ull;
-        GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv: gathered tensor larger than 2 GiB (32-bit buffer offsets): split the batch");
+        GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv: one image of the gathered tensor exceeds 2 GiB (32-bit buffer offsets)");
         p.x_bytes = (unsigned)xb;
     }
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
-    GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: output larger than 2 GiB (32-bit buffer offsets): split the batch");
+    GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
     if (gen) launch_igemm<0, 1>(p, y_elems, (hipStream_t)stream);
     else launch_igemm<0, 0>(p, y_elems, (hipStream_t)stream);
@@ -1024,6 +1037,17 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
     GIM_CHECK_ARG(dy && w && dx, "conv dgrad: null pointer");
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(mask_x && s->ups && !up_fold), "conv dgrad: mask_x with ups == 1 needs folded weights");
+    {
+        const size_t yi = (size_t)(s->H >> s->pool) * (s->W >> s->pool) * s->Cout;             // dy elements per image
+        const size_t xi = (size_t)(s->H >> (up_fold ? 1 : 0)) * (s->W >> (up_fold ? 1 : 0)) * s->Cin;   // dx (and mask) per image
+        if (s->N > 1 && (xi > yi ? xi : yi) * s->N * sizeof(float) > BUF_MAX_BYTES) {
+            gim_conv_shape a = *s, b = *s;
+            a.N = s->N / 2; b.N = s->N - a.N;
+            rc = gim_conv2d_dgrad(dy, w, sigma, mask_x, dx, &a, stream);
+            if (rc) return rc;
+            return gim_conv2d_dgrad(dy + a.N * yi, w, sigma, mask_x ? mask_x + a.N * xi : nullptr, dx + a.N * xi, &b, stream);
+        }
+    }
     ConvP p{};
     p.zero = zero_page();
     p.pos_inf = __builtin_inff();
@@ -1035,12 +1059,12 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
     p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cout;
     {
         const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.Ca * 4ull;
-        GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv: gathered tensor larger than 2 GiB (32-bit buffer offsets): split the batch");
+        GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv: one image of the gathered tensor exceeds 2 GiB (32-bit buffer offsets)");
         p.x_bytes = (unsigned)xb;
     }
     p.pre_slope = 1.f; p.mask_slope = s->pre_slope; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = 0;
     const size_t y_elems = (size_t)s->N * (s->H >> (up_fold ? 1 : 0)) * (s->W >> (up_fold ? 1 : 0)) * s->Cin;
-    GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: output larger than 2 GiB (32-bit buffer offsets): split the batch");
+    GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cout % BK) != 0 || ((uintptr_t)dy & 15);
     const bool bscalar = (s->Cin % 4) != 0 || ((uintptr_t)w & 15);
     hipStream_t st = (hipStream_t)stream;
@@ -1153,5 +1177,16 @@ extern "C" int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, f
 }
 
 extern "C" int gim_conv2d_wgrad_acc(const float* dy, const float* x, float* acc, float* bias_acc, const gim_conv_shape* s, void* stream) {
+    if (check_shape(s) == 0) {   // operands beyond the 32-bit buffer-offset range: halve the batch, both halves ADD into acc
+        const size_t yi = (size_t)(s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
+        const size_t xi = (size_t)(s->H >> s->ups) * (s->W >> s->ups) * s->Cin;
+        if (s->N > 1 && (xi > yi ? xi : yi) * s->N * sizeof(float) > BUF_MAX_BYTES) {
+            gim_conv_shape a = *s, b = *s;
+            a.N = s->N / 2; b.N = s->N - a.N;
+            const int rc = gim_conv2d_wgrad_acc(dy, x, acc, bias_acc, &a, stream);
+            if (rc) return rc;
+            return gim_conv2d_wgrad_acc(dy + a.N * yi, x + a.N * xi, acc, bias_acc, &b, stream);
+        }
+    }
     return wgrad_impl(dy, x, acc, bias_acc, 1, s, stream, true);
 }

@@ -420,3 +420,33 @@ def test_fused_adam_matches_torch_adam_form():
     assert len(st["state"]) == 4 and len(st["param_groups"]) == 2
     assert float(st["state"][0]["step"]) == 4.0
     assert relerr(st["state"][1]["exp_avg_sq"], oad.state["g0.1"]["v"]) < 1e-5
+
+
+def test_conv_operands_beyond_2gib_are_split_over_the_batch():
+    """One launch addresses an operand through 32-bit buffer offsets (2 GiB); larger batches are halved inside the C ABI
+    (images are independent; the accumulating wgrad adds the halves).  2.5 GB activations, 1x1 conv."""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    lib = _lib.load()
+    N, S, Cin, Cout = 600, 256, 16, 16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(N, S, S, Cin, device=dev(), generator=g)
+    w = torch.randn(Cout, 1, 1, Cin, device=dev(), generator=g) * 0.2
+    assert x.numel() * 4 > 2 ** 31
+    st = torch.cuda.current_stream().cuda_stream
+    sh = _lib.GimConvShape(N, S, S, Cin, Cout, 1, 0, 1.0)
+    y = torch.empty(N, S, S, Cout, device=dev())
+    _lib.check(lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st), "fwd")
+    for sl in (slice(0, 2), slice(299, 301), slice(598, 600)):      # both halves and the seam
+        ref = torch.einsum("nhwc,oc->nhwo", x[sl].double(), w.view(Cout, Cin).double())
+        assert relerr(y[sl], ref) < 3e-6
+    dx = torch.empty_like(x)
+    _lib.check(lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st), "dgrad")
+    for sl in (slice(0, 2), slice(299, 301), slice(598, 600)):
+        ref = torch.einsum("nhwo,oc->nhwc", y[sl].double(), w.view(Cout, Cin).double())
+        assert relerr(dx[sl], ref) < 3e-6
+    acc = torch.zeros(Cout * Cin, device=dev())
+    _lib.check(lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh, st), "wgrad_acc")
+    ref = torch.zeros(Cout, Cin, device=dev(), dtype=torch.float64)
+    for n0 in range(0, N, 50):
+        ref += torch.einsum("nhwo,nhwc->oc", y[n0:n0 + 50].double(), x[n0:n0 + 50].double())
+    assert relerr(acc.view(Cout, Cin), ref) < 1e-4
