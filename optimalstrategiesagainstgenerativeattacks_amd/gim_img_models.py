@@ -18,6 +18,7 @@ from .gim_basic_models import GIMMeanStdFcStat
 
 
 _TWO_STREAMS = os.environ.get("GIM_SINGLE_STREAM") is None  # A/B switch
+_PER_SAMPLE_STREAMS = os.environ.get("GIM_PER_SAMPLE_STREAMS") is not None   # one stream per (encoder, sample set): measured slower (310 vs 339 episodes/s)
 _LANE1_SIDE = os.environ.get("GIM_NO_LANE1_SIDE") is None   # A/B switch: side streams inside lane 1 as well (+5 %)
 _STREAMS = {}
 
@@ -28,12 +29,13 @@ def _use_side_streams(t):
     return _TWO_STREAMS and t.is_cuda and (ops.current_lane() == 0 or _LANE1_SIDE)
 
 
-def _side_streams(device):
-    """Two side streams per (device, lane): see ops.lane."""
+def _side_streams(device, n=2):
+    """n side streams per (device, lane): see ops.lane."""
     key = (device.type, device.index, ops.current_lane())
-    if key not in _STREAMS:
-        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-    return _STREAMS[key]
+    have = _STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
 
 
 def lane_stream(device, lane):
@@ -261,24 +263,28 @@ class GIMFaceAuthenticator(nn.Module):
     def encode_samples(self, samples):
         """src- and env-encode every sample set.  The two encoders are independent networks: they run on two HIP
         streams so that the small layers of one (8x8 and smaller maps, too few workgroups to fill 256 CUs at 16
-        episodes per GPU) overlap with the other's.  Per encoder the call order - hence the spectral-norm power
-        iteration order - is the reference's (each encoder sees the samples in list order on its own stream).
-        autograd replays each backward op on its forward stream, so the backward overlaps the same way."""
+        episodes per GPU) overlap with the other's.  The HOST call order per encoder is the reference's (samples in list
+        order), which is what fixes the order of the spectral-norm power iterations (SNPlan hands out precomputed
+        (sigma, u, v) in call order).  autograd replays each backward op on its forward stream, so the backward overlaps
+        the same way.  (One stream per (encoder, sample set) pass - GIM_PER_SAMPLE_STREAMS=1 - is slower.)"""
         cur = torch.cuda.current_stream()
         if not _use_side_streams(samples[0]):
             return ([self.src_encode_sample(s) for s in samples], [self.env_encode_sample(s) for s in samples])
-        streams = _side_streams(samples[0].device)
+        per_sample = _PER_SAMPLE_STREAMS
+        streams = _side_streams(samples[0].device, 2 * len(samples) if per_sample else 2)
         outs = []
-        for st, enc in zip(streams, (self.src_encoder, self.env_encoder)):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                feats = [_encode_sample(enc, s) for s in samples]
-            for f in feats:
+        for e, enc in enumerate((self.src_encoder, self.env_encoder)):
+            feats = []
+            for i, smp in enumerate(samples):
+                st = streams[e * len(samples) + i] if per_sample else streams[e]
+                if per_sample or i == 0:
+                    st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    f = _encode_sample(enc, smp)
                 f.record_stream(cur)  # produced on the side stream, consumed by the head on the current stream
+                smp.record_stream(st)
+                feats.append(f)
             outs.append(feats)
-        for s in samples:
-            for st in streams:
-                s.record_stream(st)
         for st in streams:
             cur.wait_stream(st)
         return outs[0], outs[1]

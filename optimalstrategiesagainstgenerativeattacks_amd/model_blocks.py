@@ -110,7 +110,7 @@ class SNConv2d(nn.Module):
         self.register_buffer("weight_v", v)
 
         self._sn_queue = collections.deque()  # (sigma, u, v) triples precomputed by an SNPlan round
-        self._fold_cache = (None, None)       # ((storage, version, optimizer epoch), folded weights F)
+        self._fold_cache = (None, None, None, None)   # ((storage, version, optimizer epoch), folded weights F, ready event, stream)
 
     def folded(self):
         """The (k+1)^2-tap folded weights for the pool / sub-pixel forms, recomputed only when weight_orig changed
@@ -121,7 +121,10 @@ class SNConv2d(nn.Module):
         if self._fold_cache[0] != key:
             with torch.no_grad():
                 f = ops._folded(ops.weight_phys(w), self.out_channels, self.in_channels, self.kernel_size)
-            self._fold_cache = (key, f)
+            # other streams (one per encoder pass) reuse F: they wait for the kernel that wrote it
+            self._fold_cache = (key, f, torch.cuda.current_stream().record_event(), torch.cuda.current_stream())
+        elif self._fold_cache[3] != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_event(self._fold_cache[2])
         return self._fold_cache[1]
 
     def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False):
