@@ -164,12 +164,21 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     // tile (shared by the N tiles) and the halo rows (shared by neighbouring M tiles) are re-read from that XCD's
     // own L2 instead of HBM.  Placement only affects speed, never results.
     int mt = blockIdx.x, nt = blockIdx.y;
-    if (p.xcd) {
+    if (p.xcd == 1) {
         const int chunk = (p.gx + 7) >> 3;
         const int x = blockIdx.x & 7, sidx = blockIdx.x >> 3;
         mt = x * chunk + sidx / p.gy;
         nt = sidx - (sidx / p.gy) * p.gy;
         if (mt >= p.gx || sidx >= chunk * p.gy) return;  // padding blocks of the rounded-up grid
+    } else if (p.xcd == 2) {
+        // weight-heavy layers (small maps, 512 channels): the WEIGHT tile is the big operand.  N-major order: XCD x walks a
+        // contiguous range of (N tile, M tile) pairs, so each XCD's L2 holds one or two weight tiles instead of all of them
+        const int total = p.gx * p.gy, chunk = (total + 7) >> 3;
+        const int x = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+        const int L = x * chunk + sidx;
+        if (sidx >= chunk || L >= total) return;
+        nt = L / p.gx;
+        mt = L - nt * p.gx;
     }
     const int m0 = mt * BM;
     const int n0 = nt * BN;
@@ -947,8 +956,13 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
     p.ksplit = (nk + p.kper - 1) / p.kper;
     if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
     p.gx = gx; p.gy = gy;
-    p.xcd = (g_xcd && (long long)gx * gy >= 64) ? 1 : 0;
-    const dim3 grid = p.xcd ? dim3(((gx + 7) / 8) * 8 * gy, 1, p.ksplit * ncls) : dim3(gx, gy, p.ksplit * ncls);
+    // XCD-aware tile orders (1: activation tile shared per XCD, 2: weight tile shared per XCD) measured against the plain
+    // order on the bench layers: equal within noise on the large layers, 9 % slower on the small-map 512-channel ones
+    // (profiles/r01_i_xcd_modes.txt), so the plain order is the default; GIM_CONV_XCD_MODE=1|2 selects the others.
+    static const int xcd_mode = getenv("GIM_CONV_XCD_MODE") ? atoi(getenv("GIM_CONV_XCD_MODE")) : 0;
+    p.xcd = (g_xcd && (long long)gx * gy >= 16) ? xcd_mode : 0;
+    const dim3 grid = p.xcd == 1 ? dim3(((gx + 7) / 8) * 8 * gy, 1, p.ksplit * ncls)
+                    : p.xcd == 2 ? dim3(((gx * gy + 7) / 8) * 8, 1, p.ksplit * ncls) : dim3(gx, gy, p.ksplit * ncls);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB>), grid, dim3(256), 0, st, p);
 }
 

@@ -29,12 +29,16 @@ def _use_side_streams(t):
     return _TWO_STREAMS and t.is_cuda and (ops.current_lane() == 0 or _LANE1_SIDE)
 
 
+_LANE1_PRIO = int(os.environ.get("GIM_LANE1_PRIO", "0"))   # stream priority of lane 1 (HIP: lower number = higher priority)
+_LANE0_PRIO = int(os.environ.get("GIM_LANE0_PRIO", "0"))   # ... of lane 0's side streams
+
+
 def _side_streams(device, n=2):
     """n side streams per (device, lane): see ops.lane."""
     key = (device.type, device.index, ops.current_lane())
     have = _STREAMS.setdefault(key, [])
     while len(have) < n:
-        have.append(torch.cuda.Stream(device=device))
+        have.append(torch.cuda.Stream(device=device, priority=_LANE1_PRIO if ops.current_lane() else _LANE0_PRIO))
     return have[:n]
 
 
@@ -42,7 +46,7 @@ def lane_stream(device, lane):
     """The main stream of a non-zero lane (lane 0 runs on the caller's current stream)."""
     key = (device.type, device.index, "lane", lane)
     if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(device=device)
+        _STREAMS[key] = torch.cuda.Stream(device=device, priority=_LANE1_PRIO)
     return _STREAMS[key]
 
 
