@@ -602,12 +602,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     // ---- VEC == 4 fast addressing (tools/micro/mfma_valu.hip: VALU work is paid in matrix-pipe time) ----
     // A (dy rows): buffer resource whose BASE advances by BK rows per step and whose num_records shrinks to the rows left
     //   in this pixel slice: lane offsets are constants and rows beyond the slice read zeros - no per-step VALU at all.
-    // B (gathered x): when one K step never crosses an image row (W % BK == 0, no on-the-fly upsample) the element offset
-    //   is  U(n, oy, ox0)  [wave-uniform, SALU]  +  L(tap, channel, tile row)  [lane constant]; only the zero-padding test
-    //   is per lane (two adds, two compares, one select per tile row).  Otherwise the generic per-row address path runs.
-    constexpr bool fastb = FASTB;  // host: VEC == 4 && ups == 0 && W % BK == 0
+    // B (gathered x): when the BK pixels of a K step lie in ONE image (H * W % BK == 0, no on-the-fly upsample) pixel `row` of
+    //   the step sits at (oy0 + (row >> logW), ox0 + (row & (W - 1))) with (oy0, ox0) wave-uniform, so the element offset is
+    //   U(n, oy0, ox0)  [SALU]  +  L(tap, channel, tile row)  [lane constant]; only the zero-padding test is per lane (two adds,
+    //   two compares, one select per tile row).  Otherwise (1x1 and 2x2 maps) the generic per-row address path runs.
+    constexpr bool fastb = FASTB;  // host: VEC == 4 && ups == 0 && H * W % BK == 0
     unsigned a_v[A_PER], b_l[B_PER];
-    int b_dx[B_PER];
+    int b_dx[B_PER], b_dy[B_PER];
     // the most negative lane constant is shifted into the base pointer so that every offset is a non-negative 32-bit value
     const int b_bias = ((g.off_y < 0 ? -g.off_y : 0) * g.Win + (g.off_x < 0 ? -g.off_x : 0)) * p.Cin * 4;
     const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - b_bias), 0, p.x_bytes + (unsigned)b_bias, 0x00020000);
@@ -620,8 +621,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int row = bk + i * B_RSTEP;
-            b_dx[i] = row * g.s_in + dw;
-            b_l[i] = (b_jok && row < BK) ? (unsigned)(((dh * g.Win + b_dx[i]) * p.Cin + ci) * 4 + b_bias) : BUF_OOB;
+            b_dy[i] = (row >> g.logW) * g.s_in + dh;
+            b_dx[i] = (row & (g.W - 1)) * g.s_in + dw;
+            b_l[i] = (b_jok && row < BK) ? (unsigned)(((b_dy[i] * g.Win + b_dx[i]) * p.Cin + ci) * 4 + b_bias) : BUF_OOB;
         }
     }
 
@@ -645,10 +647,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
                 const int n = mb >> (g.logH + g.logW);
                 const int oys = ((mb >> g.logW) & (g.H - 1)) * g.s_in, oxs = (mb & (g.W - 1)) * g.s_in;
                 const unsigned u = (unsigned)((((n * g.Hin + oys) * g.Win) + oxs) * p.Cin * 4);
-                const bool vy = (unsigned)(oys + dh) < (unsigned)He;
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
-                    const bool v = vy && (unsigned)(oxs + b_dx[i]) < (unsigned)We;
+                    const bool v = (unsigned)(oys + b_dy[i]) < (unsigned)He && (unsigned)(oxs + b_dx[i]) < (unsigned)We;
                     const f32x4 val = buf_load4(rxb, v ? b_l[i] : BUF_OOB, u);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rb[i][e] = val[e];
@@ -1178,7 +1179,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     }
     dim3 g((q.cols + q.bn - 1) / q.bn, (q.rows + q.bm - 1) / q.bm, q.ns);
     const bool vec = (s->Cin % 4 == 0) && (s->Cout % 4 == 0) && !(((uintptr_t)dy | (uintptr_t)x) & 15);
-    const bool fastb = vec && p.g.ups == 0 && (p.g.W & (BK - 1)) == 0;
+    const bool fastb = vec && p.g.ups == 0 && ((p.g.H * p.g.W) & (BK - 1)) == 0;   // a K step stays inside one image
     if (fastb) launch_wgrad<4, true>(p, q.bm, q.bn, g, (hipStream_t)stream);
     else if (vec) launch_wgrad<4, false>(p, q.bm, q.bn, g, (hipStream_t)stream);
     else launch_wgrad<1, false>(p, q.bm, q.bn, g, (hipStream_t)stream);
