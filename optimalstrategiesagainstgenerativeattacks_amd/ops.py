@@ -204,6 +204,18 @@ _QUEUES = {0: WgradQueue()}
 wgrad_queue = _QUEUES[0]
 
 
+def reset_wgrad_queues():
+    """Drop weight-gradient jobs that a failed backward pass (exception inside autograd) left behind, re-zero their arena
+    slots and re-arm the end-of-backward callback.  Called by FusedAdam.zero_grad(): a new iteration never inherits them."""
+    for q in _QUEUES.values():
+        if q.jobs or q.cb_queued:
+            for pg in q.pages:
+                if pg[1]:
+                    pg[0][:pg[1]].zero_()
+                    pg[1] = 0
+            q.jobs, q.keep, q.streams, q.cb_queued = [], [], set(), False
+
+
 def current_lane():
     return _LANE[0]
 

@@ -144,6 +144,8 @@ class FusedAdam(torch.optim.Optimizer):
     # ------------------------------------------------------------------ optimizer protocol
     def zero_grad(self, set_to_none=False):
         self._ensure()
+        from . import ops
+        ops.reset_wgrad_queues()
         self.flat_g.zero_()
         self._sync_grads()
 

@@ -450,3 +450,41 @@ def test_conv_operands_beyond_2gib_are_split_over_the_batch():
     for n0 in range(0, N, 50):
         ref += torch.einsum("nhwo,nhwc->oc", y[n0:n0 + 50].double(), x[n0:n0 + 50].double())
     assert relerr(acc.view(Cout, Cin), ref) < 1e-4
+
+
+def test_failed_backward_leaves_no_stale_weight_gradient_jobs():
+    """An exception inside autograd after some convs queued their weight-gradient jobs must not leak into the next iteration:
+    FusedAdam.zero_grad() drops the jobs, re-zeroes the arena slots and re-arms the end-of-backward callback."""
+    from optimalstrategiesagainstgenerativeattacks_amd import model_blocks as mb, ops
+    from optimalstrategiesagainstgenerativeattacks_amd.optim import FusedAdam
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    torch.manual_seed(0)
+    conv = mb.SNConv2d(16, 16, 3, padding=1).to(dev())
+    opt = FusedAdam(conv.parameters(), lr=1e-3)
+    x = torch.randn(2, 8, 8, 16, device=dev())
+
+    def grads(fail):
+        opt.zero_grad()
+        xin = x.clone().requires_grad_()
+        y = conv(Boom.apply(xin) if fail else xin)
+        y.square().sum().backward()
+        return conv.weight_orig.grad.clone()
+    state = {k_: v.clone() for k_, v in conv.state_dict().items()}
+    ref = grads(False)
+    conv.load_state_dict(state)   # same u, v for the repeat
+    with pytest.raises(RuntimeError, match="boom"):
+        grads(True)               # the conv's wgrad job is queued, then the graph raises before the flush
+    assert ops.wgrad_queue.jobs
+    conv.load_state_dict(state)
+    again = grads(False)
+    assert not ops.wgrad_queue.jobs
+    assert relerr(again, ref) < 1e-5
