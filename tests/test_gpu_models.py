@@ -519,3 +519,22 @@ def test_eval_mode_forward_vs_oracle():
     assert relerr(fake, fake_o) < 1e-3 and relerr(out, out_o) < 1e-3
     for k_, v in before.items():
         assert torch.equal(v, au.state_dict()[k_]), k_
+
+
+def test_stale_spectral_norm_state_is_refused():
+    """The per-round (sigma, u, v) live in two alternating persistent buffer sets; a backward pass whose set has been overwritten
+    by later forwards (third forward of the same model before the first backward) raises instead of using stale values."""
+    au, _ = _product_models("stale", "16_1_32")
+    _, real, si, _ = episode("stale", 2, 1, 3, 4, 1, 16, 32)
+    real, si = real.float().to(dev()), si.float().to(dev())
+    au.train()
+    out1 = au(test_sample=real, si_sample=si)
+    out2 = au(test_sample=real, si_sample=si)
+    out2.sum().backward()            # two forwards before a backward are fine
+    out3 = au(test_sample=real, si_sample=si)
+    out4 = au(test_sample=real, si_sample=si)
+    with pytest.raises(RuntimeError, match="spectral-norm state"):
+        out1.sum().backward()
+    del out3, out4
+    from optimalstrategiesagainstgenerativeattacks_amd import ops as gops
+    gops.reset_wgrad_queues()   # the refused backward had already queued the head's weight-gradient jobs
