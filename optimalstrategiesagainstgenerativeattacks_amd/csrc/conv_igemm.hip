@@ -134,7 +134,10 @@ template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB>
 __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
     constexpr bool BSCALAR = (GENF & 2) != 0;
-    constexpr int WAVES_N = BN / (32 * TN);
+    // BN == 16: narrow outputs (<= 16 channels: RGB layers, the 6-channel image pair) use the 16x16x4 MFMA - a 32-wide tile
+    // would spend 81-91 % of its MFMA work on padding columns.  One wave = 32*TM rows x 16 columns = 2*TM accumulator blocks.
+    constexpr bool N16 = BN == 16;
+    constexpr int WAVES_N = N16 ? 1 : BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int LDK = KB + 4;                    // padded k-row (conflict-free ds_read_b128 for KB = 16 and 32)
@@ -421,6 +424,11 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    constexpr int NB16 = 2 * TM;                   // N16: 16-row accumulator blocks per wave
+    const int r16 = lane & 15, q16 = lane >> 4;    // N16: row / column within a block, k quad
+    f32x4 acc16[NB16];
+#pragma unroll
+    for (int i = 0; i < NB16; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk_all = (p.Ktot + KB - 1) / KB;
     const int ks0 = kslice * p.kper;
@@ -439,6 +447,26 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
 #endif
         const float* Ab = As + buf * A_SZ;
         const float* Bb = Bs + buf * B_SZ;
+        if constexpr (N16) {
+            // v_mfma_f32_16x16x4_f32: lane (r16, q16) feeds A[row r16][k] and B[k][col r16] with k = 4*q16 + t in step t: one
+            // ds_read_b128 per operand block serves 4 MFMAs (same k permutation on both operands)
+#pragma unroll
+            for (int kk = 0; kk < KB / 16; ++kk) {
+                f32x4 a[NB16], b;
+#pragma unroll
+                for (int i = 0; i < NB16; ++i) a[i] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + 16 * i + r16) * LDK + 16 * kk + 4 * q16]);
+                if constexpr (BMODE == 0) {
+                    b = *reinterpret_cast<const f32x4*>(&Bb[r16 * LDK + 16 * kk + 4 * q16]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = Bb[(16 * kk + 4 * q16 + e) * BN + r16];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < NB16; ++i) acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[e], acc16[i], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < KB / 8; ++kk) {
             f32x4 a[TM], b[TN];
@@ -496,6 +524,28 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (p.res && first) ? ybytes : 0u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_x, 0, p.mask_x ? ybytes : 0u, 0x00020000);
         const unsigned rowb = (unsigned)p.Cb * 4u;
+        if constexpr (N16) {   // accumulator block i, register e: row 16*i + 4*q16 + e, column r16
+            const int co = n0 + r16;
+            const bool cok = co < p.Cb;
+            const float bv = (p.bias && first && cok) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NB16; ++i) {
+                const unsigned voff = cok ? (unsigned)(((m0 + wm0 + 16 * i + 4 * q16) * p.Cb + co) * 4) : BUF_OOB;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned soff = (unsigned)e * rowb;
+                    float v = acc16[i][e] * scale + bv;
+                    if (p.res && first) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, voff, soff, 0));
+                    if (p.mask_x) {
+                        const float xm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, voff, soff, 0));
+                        v *= (xm > 0.f ? 1.0f : p.mask_slope);
+                    }
+                    if (p.ksplit > 1) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, ry, voff, soff, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, soff, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -520,6 +570,29 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
         return;
     }
     const int Ho = g.H * g.os, Wo = g.W * g.os;
+    auto store_remapped = [&](int m, int co, float a, float bv) {
+        if (m >= p.M) return;
+        const int n = m >> (g.logH + g.logW);
+        const int oy = ((m >> g.logW) & (g.H - 1)) * g.os + g.py;
+        const int ox = (m & (g.W - 1)) * g.os + g.px;
+        const long long o = (((long long)n * Ho + oy) * Wo + ox) * p.Cb + co;
+        const long long ro = p.res_ups ? (((long long)n * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * p.Cb + co : o;
+        float v = a * scale + bv;
+        if (p.res && first) v += p.res[ro];
+        if (p.mask_x) v *= (p.mask_x[o] > 0.f ? 1.0f : p.mask_slope);
+        if (p.ksplit > 1) atomicAdd(&p.y[o], v);
+        else p.y[o] = v;
+    };
+    if constexpr (N16) {
+        const int co = n0 + r16;
+        if (co >= p.Cb) return;
+        const float bv = (p.bias && first) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NB16; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_remapped(m0 + wm0 + 16 * i + 4 * q16 + e, co, acc16[i][e], bv);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -913,6 +986,7 @@ static int g_force_ksplit = getenv("GIM_CONV_KSPLIT") ? atoi(getenv("GIM_CONV_KS
 static int g_force_tile = getenv("GIM_CONV_TILE") ? atoi(getenv("GIM_CONV_TILE")) : 0;
 static int g_wgrad_target = getenv("GIM_WGRAD_TARGET") ? atoi(getenv("GIM_WGRAD_TARGET")) : 0;   // 0: table / default
 static const bool g_use_table = getenv("GIM_CONV_NO_TABLE") == nullptr;
+static const bool g_no_n16 = getenv("GIM_CONV_NO_N16") != nullptr;   // A/B switch
 
 // Launch configurations measured per layer shape on an MI355X (tools/conv_autotune.py writes conv_tune_table.inc):
 // {kind (0 fwd-style, 1 dgrad-style, 2 wgrad), M, Ca, Cb, Ktot, parity classes, tile config, split-K | wgrad slice target}.
@@ -1001,8 +1075,10 @@ static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
         int cfg = (want == 64 || want == 1264) ? want : (M <= 64 ? 64 : mid_cfg);
         if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st);
         else launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st);
-    } else {
+    } else if (Cb > 16 || g_no_n16) {
         launch_cfg<128, 32, 1, 1, BMODE, GEN>(pt, y_elems, st);
+    } else {
+        launch_cfg<128, 16, 1, 1, BMODE, GEN>(pt, y_elems, st);   // 16x16x4 MFMA tile for <= 16 output channels
     }
 }
 
