@@ -146,6 +146,12 @@ int gim_wgrad_finish_batched(const gim_wgrad_job* jobs, int n_jobs, const int32_
 /* Column sums: out[c] = sum_r x[r][c]  (bias gradients; rows x C). scratch >= 256*C floats. */
 int gim_colsum(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream);
 
+/* gim_colsum that ADDS into out (bias gradients straight into the optimizer's flat gradient bucket). */
+int gim_colsum_acc(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream);
+/* Two short column sums in one launch: out_a[c] (+)= sum_r a[r][c], out_b[c] (+)= sum_r b[r][c]  (InstanceNorm affine
+ * gradients from the per-image partials of gim_norm_bwd; accumulate != 0 adds into the outputs). */
+int gim_colsum2(const float* a, const float* b, float* out_a, float* out_b, int rows, int C, int accumulate, void* stream);
+
 /* Instance norm / AdaIN over H*W per (n, c) on NHWC data.
  *  mode 0: nn.InstanceNorm2d(affine=True), biased var, eps inside the sqrt (models/gim_img_models.py:126,
  *          models/model_blocks.py:747-748);  scale/shift are [C].

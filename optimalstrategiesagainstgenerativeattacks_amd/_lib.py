@@ -59,6 +59,8 @@ SIGNATURES = {
     "gim_slice_channels": [P, P, c_int64, c_int, c_int, P],
     "gim_conv2d_wgrad_acc": [P, P, P, P, SP, P],
     "gim_wgrad_finish_batched": [P, c_int, P, c_int, P, c_int, P],
+    "gim_colsum_acc": [P, P, P, c_int64, c_int, P],
+    "gim_colsum2": [P, P, P, P, c_int, c_int, c_int, P],
     "gim_conv_tune_override": [c_int, c_int, c_int],
     "gim_episode_gather": [P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_maxpool_gather": [P, P, P, P, c_int, c_int, c_int, c_float, P],

@@ -695,3 +695,43 @@ extern "C" int gim_episode_gather(const uint8_t* bank, const int32_t* idx, const
     hipLaunchKernelGGL(episode_gather_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, bank, idx, flip, out, H, W, C, n);
     return gim_check_launch("gim_episode_gather");
 }
+
+// ---------------------------------------------------------------- small-gradient reductions that ADD into the flat gradient bucket
+// out_a[c] (+)= sum_r a[r][c],  out_b[c] (+)= sum_r b[r][c]   for short row counts (InstanceNorm affine gradients: rows = images):
+// one launch instead of two two-stage column sums plus two AccumulateGrad adds.
+__global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out_a,
+                                                      float* __restrict__ out_b, int rows, int C, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float sa = 0.f, sb = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        sa += a[(long long)r * C + c];
+        sb += b[(long long)r * C + c];
+    }
+    out_a[c] = accumulate ? out_a[c] + sa : sa;
+    out_b[c] = accumulate ? out_b[c] + sb : sb;
+}
+extern "C" int gim_colsum2(const float* a, const float* b, float* out_a, float* out_b, int rows, int C, int accumulate, void* stream) {
+    GIM_CHECK_ARG(a && b && out_a && out_b && rows > 0 && C > 0, "colsum2: bad args");
+    hipLaunchKernelGGL(colsum2_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, out_a, out_b, rows, C, accumulate);
+    return gim_check_launch("gim_colsum2");
+}
+
+__global__ __launch_bounds__(256) void colsum_final_acc_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(long long)p * C + c];
+    out[c] += s;
+}
+// out[c] += sum_r x[r][c]  (gim_colsum that ADDS: bias gradients straight into the optimizer's gradient bucket)
+extern "C" int gim_colsum_acc(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream) {
+    GIM_CHECK_ARG(x && out && scratch && rows > 0 && C > 0, "colsum_acc: bad args");
+    long long P = (rows + 63) / 64;
+    if (P > 256) P = 256;
+    const long long rows_per = (rows + P - 1) / P;
+    P = (rows + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 63) / 64, (int)P), dim3(256), 0, (hipStream_t)stream, x, scratch, (long long)rows, C, rows_per);
+    hipLaunchKernelGGL(colsum_final_acc_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)P, C);
+    return gim_check_launch("gim_colsum_acc");
+}

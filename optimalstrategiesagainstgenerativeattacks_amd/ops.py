@@ -383,9 +383,13 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
         q.add((src, bsrc or 0, _p(wp) if sn else 0, _p(sigma) or 0, _p(u_s) or 0, _p(v_s) or 0, tmp or 0, part or 0,
                _p(acc_w), _p(acc_b) or 0, Cout, Cin, KH, (2 if ups else 1) if fold else 0, n_chunks), (sigma, u_s, v_s))
         if want_b and not slab_bias:
-            db = torch.empty(Cout, device=dev, dtype=torch.float32)
             scr = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
-            check(lib.gim_colsum(_p(dy), _p(db), _p(scr), Mo, Cout, st), "colsum")
+            tgt_b = _grad_target(bias)
+            if tgt_b is not None:
+                check(lib.gim_colsum_acc(_p(dy), _p(tgt_b), _p(scr), Mo, Cout, st), "colsum_acc")
+            else:
+                db = torch.empty(Cout, device=dev, dtype=torch.float32)
+                check(lib.gim_colsum(_p(dy), _p(db), _p(scr), Mo, Cout, st), "colsum")
         return None, db
     if want_b and acc_b is None:
         db = torch.empty(Cout, device=dev, dtype=torch.float32)
@@ -489,6 +493,7 @@ class NormFn(Function):
     def forward(ctx, x, scale, shift, res, mode, eps):
         lib = _lib.load()
         x = _req(x, "x")
+        scale_in, shift_in = scale, shift
         scale = _req(scale, "scale")
         shift = _req(shift, "shift")
         N, H, W, C = x.shape
@@ -499,6 +504,7 @@ class NormFn(Function):
         check(lib.gim_norm_fwd(_p(x), _p(scale), _p(shift), _p(res), _p(y), _p(stats), N, H * W, C, mode, eps, _stream()), "norm_fwd")
         ctx.save_for_backward(x, scale, stats)
         ctx.cfg = (N, H * W, C, mode, res is not None)
+        ctx.scale_param, ctx.shift_param = (scale_in, shift_in) if mode == 0 else (None, None)
         return y
 
     @staticmethod
@@ -514,11 +520,19 @@ class NormFn(Function):
         dsh = torch.empty((N, C), device=x.device, dtype=torch.float32)
         check(lib.gim_norm_bwd(_p(dy), _p(x), _p(scale), _p(stats), _p(dx), _p(dsc), _p(dsh), N, HW, C, mode, st), "norm_bwd")
         if mode == 0:
-            dscale = torch.empty(C, device=x.device, dtype=torch.float32)
-            dshift = torch.empty(C, device=x.device, dtype=torch.float32)
-            scratch = torch.empty(256 * C, device=x.device, dtype=torch.float32)
-            check(lib.gim_colsum(_p(dsc), _p(dscale), _p(scratch), N, C, st), "colsum")
-            check(lib.gim_colsum(_p(dsh), _p(dshift), _p(scratch), N, C, st), "colsum")
+            # affine gradients: one launch, added straight into the parameters' .grad when that is the optimizer's flat
+            # bucket (no AccumulateGrad add kernels: 6 launches -> 1 per InstanceNorm layer)
+            tgt_s, tgt_b = _grad_target(ctx.scale_param), _grad_target(ctx.shift_param)
+            if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+                dscale = dshift = None
+            elif (tgt_s is not None and tgt_b is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+                  and not torch.is_grad_enabled()):
+                check(lib.gim_colsum2(_p(dsc), _p(dsh), _p(tgt_s), _p(tgt_b), N, C, 1, st), "colsum2")
+                dscale = dshift = None
+            else:
+                dscale = torch.empty(C, device=x.device, dtype=torch.float32)
+                dshift = torch.empty(C, device=x.device, dtype=torch.float32)
+                check(lib.gim_colsum2(_p(dsc), _p(dsh), _p(dscale), _p(dshift), N, C, 0, st), "colsum2")
         else:
             dscale, dshift = dsc.view_as(scale), dsh.view_as(scale)
         return dx, dscale, dshift, (dy if has_res else None), None, None

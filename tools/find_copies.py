@@ -66,3 +66,21 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         G.gim_step(G.DataParallelMock(tr), leaked, real, si, overlap=False)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="count", row_limit=25, max_name_column_width=60))
+for ev in prof.key_averages():
+    if any(w in ev.key.lower() for w in ("copy", "memcpy", "fill", "zero", "memset")):
+        print("%-60s count %d" % (ev.key[:60], ev.count))
+# call sites of the copies: stack-enabled second pass
+with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof2:
+    if mode == "fwd":
+        tr.impersonator_sample(leaked)
+    else:
+        G.gim_step(G.DataParallelMock(tr), leaked, real, si, overlap=False)
+    torch.cuda.synchronize()
+import collections as _c
+sites2 = _c.Counter()
+for ev in prof2.events():
+    if ev.name in ("aten::copy_", "aten::zero_", "aten::fill_", "aten::zeros", "aten::clone", "aten::contiguous", "hipMemcpyAsync", "aten::add", "aten::add_"):
+        st = [f for f in (ev.stack or []) if "optimalstrategies" in f]
+        sites2[(ev.name, st[0] if st else "?")] += 1
+for k, v in sites2.most_common(25):
+    print(v, k)
