@@ -55,7 +55,7 @@ def measured_hbm_traffic(workload, B):
     """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE; profiles/*hbm_traffic*.json).  bench.py cannot run the profiler on itself, so this
     is the last profiled value for the workload, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic_%s_B%d.json" % (workload, B))
+    path = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic_%s_B%d.json" % (workload, B))
     try:
         with open(path) as f:
             return float(json.load(f)["hbm_bytes_per_step"])
