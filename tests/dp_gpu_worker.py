@@ -1,0 +1,51 @@
+"""Worker of tests/test_gpu_models.py::test_two_rank_data_parallel_step_on_gpu (run as a child process per rank)."""
+import os
+import sys
+import tempfile
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.helpers import episode, filled_sd, load_keys  # noqa: E402
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    dev = torch.device("cuda:0")
+    cfg, (s, c, d) = "16_1_32", (16, 1, 32)
+    B, m, n, k = 4, 1, 3, 4
+    keys = load_keys(cfg)
+    au, im = G.get_au(s, c, d), G.get_im(s, c, d)
+    au.load_state_dict(filled_sd(keys["au"], "dpg/au/", torch.float32))
+    im.load_state_dict(filled_sd(keys["im"], "dpg/im/", torch.float32))
+    with tempfile.TemporaryDirectory() as td:
+        tr = G.GIMImgTrainer(td, m, n, k, au.to(dev), im.to(dev), 1e-3, 1e-3, 1e-4, reg_param=0.0)
+    trainer = G.EpisodeParallel(tr) if world > 1 else G.DataParallelMock(tr)
+    if world > 1:
+        trainer.broadcast_parameters()
+    outs = []
+    for it in range(2):
+        leaked, real, si, z = [t.float().to(dev) for t in episode("dpg/%d" % it, B, m, n, k, c, s, d)]
+        if world > 1:
+            leaked, real, si, z = trainer.shard(leaked, real, si, z)
+        tr.do_global_step()
+        gi, di = G.gim_step(trainer, leaked, real, si, z=z)
+        outs.append((gi[0].item(), di[0].item()))
+    torch.cuda.synchronize()
+    if rank == 0:
+        sd = {"au." + k_: v.cpu() for k_, v in au.state_dict().items()}
+        sd.update({"im." + k_: v.cpu() for k_, v in im.state_dict().items()})
+        torch.save({"state": sd, "outs": outs}, out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

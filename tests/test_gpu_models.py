@@ -538,3 +538,28 @@ def test_stale_spectral_norm_state_is_refused():
     del out3, out4
     from optimalstrategiesagainstgenerativeattacks_amd import ops as gops
     gops.reset_wgrad_queues()   # the refused backward had already queued the head's weight-gradient jobs
+
+
+def test_two_rank_data_parallel_step_on_gpu(tmp_path):
+    """Two processes (gloo; both ranks on the one GPU of the box), each with half of the episodes: after two overlapped
+    gim_step iterations with the gradient all-reduce inside FusedAdam the replicas hold the parameters of the single-process
+    run on the whole batch (the local losses are the means over the local episodes)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "dp_gpu_worker.py")
+    port = str(29600 + os.getpid() % 1000)
+    single, dp = str(tmp_path / "single.pt"), str(tmp_path / "dp.pt")
+    subprocess.run([sys.executable, worker, "0", "1", port, single], check=True, timeout=600)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, dp]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    a, b = torch.load(single), torch.load(dp)
+    bad = []
+    for k_ in a["state"]:
+        e = relerr(b["state"][k_], a["state"][k_])
+        if e > (5.5e-2 if k_.endswith(".bias") else 5e-3):   # zero-gradient biases random-walk by +-lr (see the overlap test)
+            bad.append((k_, e))
+    assert not bad, bad[:5]
+    # rank 0 saw episodes 0-1 only: its losses differ from the global means, but the first generator loss is within the batch spread
+    assert abs(a["outs"][0][0] - b["outs"][0][0]) < 0.5
