@@ -563,3 +563,39 @@ def test_two_rank_data_parallel_step_on_gpu(tmp_path):
     assert not bad, bad[:5]
     # rank 0 saw episodes 0-1 only: its losses differ from the global means, but the first generator loss is within the batch spread
     assert abs(a["outs"][0][0] - b["outs"][0][0]) < 0.5
+
+
+def test_authentication_eval_agents_on_episode_bank():
+    """authentication_eval (agents.py / authentication_score.py / eval_gim_on_authentication.py:25-106) on the engine: the
+    agents run both networks in eval mode; accuracy / AUC equal a by-hand evaluation of the same batches; a replay
+    impersonator (copies of the leaked image) is served through the same interface."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    from optimalstrategiesagainstgenerativeattacks_amd import authentication_eval as ae
+    S, C, D, m, n, k = 16, 1, 32, 1, 3, 4
+    au, im = _product_models("aeval", "16_1_32")
+    imgs, offs = G.synthetic_bank(8, 10, S, C, dev(), seed=2)
+    ds = G.EpisodeBank(imgs, offs, m, n, k, example_cnt_per_class=1, mirror=False, seed=5)
+    authenticator = ae.get_gim_authenticator(au)
+    impersonator = ae.get_gim_impersonator(im, {"remove_noise_mean": True})
+    torch.manual_seed(3)
+    acc, acc_f, acc_r, auc = ae.eval_authenticator_and_impersonator(dev(), ds, 4, 0, authenticator, impersonator)
+    assert not au.training and not im.training
+    for v in (acc, acc_f, acc_r, auc):
+        assert 0.0 <= float(v) <= 1.0
+    # by hand on the same batches (same bank seed -> same episodes, same z stream)
+    ds2 = G.EpisodeBank(imgs, offs, m, n, k, example_cnt_per_class=1, mirror=False, seed=5)
+    torch.manual_seed(3)
+    o_r, o_f = [], []
+    with torch.no_grad():
+        for b in ds2.gpu_batches(4, True):
+            o_r.append(au(test_sample=b["real_sample"], si_sample=b["si_sample"]).view(-1))
+            fake = im(leaked_sample=b["leaked_sample"], n=n, remove_noise_mean=True)
+            o_f.append(au(test_sample=fake, si_sample=b["si_sample"]).view(-1))
+    o_r, o_f = torch.cat(o_r), torch.cat(o_f)
+    acc2 = 0.5 * ((o_r >= 0).float().mean() + (o_f < 0).float().mean())
+    assert abs(float(acc) - float(acc2)) < 1e-6
+    # replay impersonator through the agent interface
+    rep = ae.Impersonator(ae.replay_impersonator)
+    b = next(iter(ds2.gpu_batches(4, False)))
+    fake = rep.act(leaked_sample=b["leaked_sample"], n=n)
+    assert fake.shape == b["real_sample"].shape and torch.equal(fake[:, 0], b["leaked_sample"][:, 0])

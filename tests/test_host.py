@@ -244,3 +244,17 @@ def test_logger_mirror_and_training_loop_cadence(tmp_path):
     assert l2.stats == logger.stats
     logger.add_imgs(torch.rand(7, 3, 4, 4), "cat a", "k", 3)
     assert len(os.listdir(str(tmp_path / "imgs" / "cat_a" / "k"))) == 1
+
+
+def test_roc_auc_matches_sklearn():
+    """authentication_eval.roc_auc (rank statistic with mid-ranks) == sklearn.metrics.roc_auc_score, ties included."""
+    import numpy as np
+    from sklearn.metrics import roc_auc_score
+    from optimalstrategiesagainstgenerativeattacks_amd.authentication_eval import comp_acc, roc_auc
+    rng = np.random.default_rng(0)
+    for trial in range(5):
+        y = rng.integers(0, 2, 200)
+        s = np.round(rng.normal(size=200) + 0.7 * y, 1 if trial % 2 else 6)   # coarse rounding -> ties
+        assert abs(roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12
+    acc, acc_f, acc_r = comp_acc(torch.tensor([1, 1, 0, 1]), torch.tensor([0, 1, 0, 0]))
+    assert float(acc_r) == 0.75 and float(acc_f) == 0.75 and float(acc) == 0.75
