@@ -17,8 +17,13 @@ import sys
 import tempfile
 import time
 
-import torch
-import torch.distributed as dist
+# Eight HIP hardware queues instead of the default four (read by the HIP runtime when it initialises): the engine's four
+# streams, torch's copy streams and RCCL's then sit on queues of their own instead of aliasing by creation order
+# (optimalstrategiesagainstgenerativeattacks_amd/gim_img_models.py, role -> stream map; profiles/r01_k_stream_map.txt)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -164,7 +169,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("GIM_FORCE_ALLREDUCE"):   # the latter: one-rank RCCL rehearsal (needs MASTER_ADDR/PORT)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:

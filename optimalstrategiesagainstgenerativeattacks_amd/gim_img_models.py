@@ -29,25 +29,44 @@ def _use_side_streams(t):
     return _TWO_STREAMS and t.is_cuda and (ops.current_lane() == 0 or _LANE1_SIDE)
 
 
-_LANE1_PRIO = int(os.environ.get("GIM_LANE1_PRIO", "0"))   # stream priority of lane 1 (HIP: lower number = higher priority)
-_LANE0_PRIO = int(os.environ.get("GIM_LANE0_PRIO", "0"))   # ... of lane 0's side streams
+# Role -> stream map.  Roles: 0, 1 = lane 0's two side streams, 2 = lane 1's main stream, 3, 4 = lane 1's side streams
+# (lane 0's main stream is the caller's).  Roles with the same id share ONE torch stream: their work is serialized in issue
+# order.  Which roles may run concurrently matters more than how many streams exist (MI355X, 64x64x3, 16 episodes,
+# profiles/r01_k_stream_map.txt): every role on a hardware queue of its own (GPU_MAX_HW_QUEUES=8, map 0,1,2,3,4) runs
+# 240-255 episodes/s - four conv streams at once starve the critical generator lane - while with HIP's default of 4 hardware
+# queues that same map gives 346 or 292 depending on which streams happen to alias onto one queue (creating an RCCL
+# communicator shifts the assignment by one).  The default below keeps at most three conv streams in flight (lane 1's
+# first encoder on lane 1's own stream, its second one behind lane 0's first side stream): 335-340 episodes/s with 4 or 8
+# hardware queues, with or without RCCL.
+_STREAM_MAP = [int(v) for v in os.environ.get("GIM_STREAM_MAP", "0,1,2,2,0").split(",")]
+assert len(_STREAM_MAP) == 5, "GIM_STREAM_MAP: five comma-separated stream ids (roles 0..4)"
+_POOL = {}
+
+
+def _role_stream(device, role):
+    key = (device.type, device.index, _STREAM_MAP[role])
+    if key not in _POOL:
+        _POOL[key] = torch.cuda.Stream(device=device)
+    return _POOL[key]
 
 
 def _side_streams(device, n=2):
-    """n side streams per (device, lane): see ops.lane."""
-    key = (device.type, device.index, ops.current_lane())
+    """The side streams of the current lane (see ops.lane)."""
+    assert n == 2 or _PER_SAMPLE_STREAMS
+    lane = ops.current_lane()
+    if n == 2:
+        return [_role_stream(device, 3 * lane), _role_stream(device, 3 * lane + 1)]
+    key = (device.type, device.index, "many", lane)
     have = _STREAMS.setdefault(key, [])
     while len(have) < n:
-        have.append(torch.cuda.Stream(device=device, priority=_LANE1_PRIO if ops.current_lane() else _LANE0_PRIO))
+        have.append(torch.cuda.Stream(device=device))
     return have[:n]
 
 
 def lane_stream(device, lane):
-    """The main stream of a non-zero lane (lane 0 runs on the caller's current stream)."""
-    key = (device.type, device.index, "lane", lane)
-    if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(device=device, priority=_LANE1_PRIO)
-    return _STREAMS[key]
+    """The main stream of lane 1 (lane 0 runs on the caller's current stream)."""
+    assert lane == 1
+    return _role_stream(device, 2)
 
 
 class Encoder(nn.Module):

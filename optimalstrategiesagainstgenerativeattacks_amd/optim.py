@@ -13,6 +13,8 @@ Replaces the two ``torch.optim.Adam`` instances of the reference trainer
 ``state_dict()`` / ``load_state_dict()`` keep torch.optim.Adam's format (per-parameter ``step`` /
 ``exp_avg`` / ``exp_avg_sq``; group keys lr, betas, eps, weight_decay, amsgrad), so reference checkpoints load.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -46,12 +48,16 @@ def _pad(n, align=64):
     return (n + align - 1) // align * align
 
 
+# rehearsal switch: issue the collective even with one rank (exercises the RCCL call path on a one-GPU box)
+_FORCE_ALLREDUCE = os.environ.get("GIM_FORCE_ALLREDUCE") is not None
+
+
 def all_reduce_grads_(flat_g):
     """Data-parallel gradient exchange: ONE all-reduce(sum) of a flat gradient bucket over RCCL/xGMI (gloo in
     the CPU tests).  Each rank's bucket holds the gradient of its local mean loss, so the global-batch
     gradient is the returned scale (1/world_size) times the reduced bucket; the scale is folded into the
     Adam kernel.  No-op (scale 1) when torch.distributed is not initialised."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_ALLREDUCE):
         dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
         return 1.0 / dist.get_world_size()
     return 1.0
