@@ -117,6 +117,13 @@ int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, const int32_t
  * heuristics.  Process-wide, not thread-safe: for tuning runs only. */
 int gim_conv_tune_override(int tile_cfg, int ksplit, int wgrad_target);
 
+/* Matrix path of the k-contiguous conv / linear contraction (replaces nothing in the reference: F.conv2d has one fp32 path).
+ * 0 = v_mfma_f32_32x32x2_f32; 1 = "bf16x3": every fp32 operand is split exactly into three bf16 numbers and six partial
+ * products are accumulated in fp32 on the bf16 matrix pipe - fp32-level accuracy at 2.67x fewer matrix-pipe cycles (layers
+ * the bf16x3 kernel does not cover keep path 0).  Returns the previous mode; mode < 0 only queries.  GIM_CONV_PREC sets the
+ * start value.  Process-wide. */
+int gim_conv_precision(int mode);
+
 /* Accumulating weight gradient: ADDS the gradient of one convolution (raw, un-finished: dW, dF or G layout as in
  * gim_conv2d_wgrad) into `acc` / `bias_acc` with float atomics and clears nothing - the caller hands in zeroed (or
  * partially accumulated) buffers, typically slots of one arena cleared once per backward pass. */

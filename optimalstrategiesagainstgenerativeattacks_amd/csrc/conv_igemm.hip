@@ -84,6 +84,7 @@ struct ConvP {
     const float* zero;  // 16 bytes of zeros (out-of-range lanes load from here)
     unsigned x_bytes;   // size of the gathered tensor (buffer-resource range of the fast path)
     int tune_ks;        // host only: split-K factor from the tuning table (0 = heuristic)
+    int prec;           // host only: 1 = bf16x3 matrix path where the kernel has one
     float pos_inf;      // +infinity as a run-time value
     float pre_slope, mask_slope, out_scale;
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
@@ -130,10 +131,44 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB>
-__global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const ConvP p) {
+// PREC 1 ("bf16x3"): the same fp32 contraction on the bf16 matrix pipe.  Every fp32 operand element is split EXACTLY into
+// three bf16 numbers when its tile is written to LDS (x = hi + mid + lo, truncation split of the 24-bit significand into
+// 8 + 8 + 8 bits) and six of the nine partial products are accumulated by v_mfma_f32_32x32x16_bf16 in fp32:
+// hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi; the dropped terms are <= 2^-23 |x*y|, the level of the fp32 MFMA's own
+// rounding (tools/micro/bf16x3_gemm.hip: error vs fp64 1.2e-7 against 1.4e-7 for v_mfma_f32_32x32x2_f32).  Six 32-cycle
+// MFMAs per 32x32x16 block replace eight 64-cycle ones: 2.67x fewer matrix-pipe cycles for 5.5 VALU per staged element.
+// LDS row = [hi: 16 bf16][mid][lo] + 16 B pad = 28 dwords: conflict-free ds_read_b128 / ds_write_b64.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define X3_LDR 28
+
+// 4 consecutive-k floats -> 3 planes x 4 bf16, written as three ds_write_b64 (dst = row base + 2 * k-quad, in dwords)
+__device__ __forceinline__ void x3_split_store(unsigned* dst, const f32x4& x) {
+    unsigned r1[4], r2[4], xb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xe = x[e];   // by value: __builtin_bit_cast of a vector-element lvalue reads element 0
+        xb[e] = __builtin_bit_cast(unsigned, xe);
+        const float d1 = xe - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);         // exact
+        r1[e] = __builtin_bit_cast(unsigned, d1);
+        const float d2 = d1 - __builtin_bit_cast(float, r1[e] & 0xFFFF0000u);         // exact, <= 8 significant bits
+        r2[e] = __builtin_bit_cast(unsigned, d2);
+    }
+    // v_perm_b32: (upper half of the second) << 16 | upper half of the first = two truncated bf16, element order kept
+    u32x2 hi = {__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
+    u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    *reinterpret_cast<u32x2*>(dst) = hi;
+    *reinterpret_cast<u32x2*>(dst + 8) = mid;
+    *reinterpret_cast<u32x2*>(dst + 16) = lo;
+}
+
+template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB, int PREC = 0>
+__global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)) : (KB == 16 ? 4 : 2)) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
     constexpr bool BSCALAR = (GENF & 2) != 0;
+    constexpr bool X3 = PREC == 1;
+    static_assert(!X3 || (BMODE == 0 && GENF == 0 && BN >= 32 && KB == 16), "bf16x3: k-contiguous fast path only");
     // BN == 16: narrow outputs (<= 16 channels: RGB layers, the 6-channel image pair) use the 16x16x4 MFMA - a 32-wide tile
     // would spend 81-91 % of its MFMA work on padding columns.  One wave = 32*TM rows x 16 columns = 2*TM accumulator blocks.
     constexpr bool N16 = BN == 16;
@@ -149,8 +184,9 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
     constexpr int B_U = BN / 4;                    // BMODE 1, vector: float4 units per k-row
     constexpr int B_RSTEP = 256 / B_U;
     constexpr int B_PER4 = (KB + B_RSTEP - 1) / B_RSTEP;
-    constexpr int A_SZ = BM * LDK;
-    constexpr int B_SZ = (BMODE == 0) ? BN * LDK : KB * BN;
+    constexpr int LDA = X3 ? X3_LDR : LDK;         // dwords per k-row of an LDS tile
+    constexpr int A_SZ = BM * LDA;
+    constexpr int B_SZ = (BMODE == 0) ? BN * LDA : KB * BN;
     __shared__ __attribute__((aligned(16))) float lds[2 * A_SZ + 2 * B_SZ];
     float* As = lds;
     float* Bs = lds + 2 * A_SZ;
@@ -392,13 +428,18 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
             // (tools/isa_waitcnt_check.py), which exposes the global-load latency every K-step
 #pragma unroll
             for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.pre_slope, p.pos_inf);  // med3(x, s*x, +inf) = max(x, s*x) in 2 VALU (a literal inf folds back into the 3-op canonicalising max)
-            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
+            if constexpr (X3) x3_split_store(reinterpret_cast<unsigned*>(As) + buf * A_SZ + (arow + RP * i) * LDA + (aq >> 1), ra[i]);
+            else *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
         }
         if constexpr (BMODE == 0) {
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) {
                 const int row = arow + RP * i;
-                if (row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
+                if constexpr (X3) {
+                    if (row < BN) x3_split_store(reinterpret_cast<unsigned*>(Bs) + buf * B_SZ + row * LDA + (aq >> 1), rb0[i]);
+                } else {
+                    if (row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
+                }
             }
         } else {
             if constexpr (BSCALAR) {
@@ -466,6 +507,29 @@ __global__ __launch_bounds__(256, KB == 16 ? 4 : 2) void conv_igemm_kernel(const
 #pragma unroll
                     for (int i = 0; i < NB16; ++i) acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[e], acc16[i], 0, 0, 0);
             }
+        } else if constexpr (X3) {
+            // v_mfma_f32_32x32x16_bf16: lane (r, h) feeds row r, k = 8h .. 8h+7 of each plane: one ds_read_b128 per operand plane
+            const unsigned* Au = reinterpret_cast<const unsigned*>(Ab);
+            const unsigned* Bu = reinterpret_cast<const unsigned*>(Bb);
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Au + (wm0 + 32 * i + r) * LDA + 8 * pl + 4 * h));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bu + (wn0 + 32 * j + r) * LDA + 8 * pl + 4 * h));
+            }
+            // (plane of A, plane of B) per term, small terms first
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[j][TB[q]], acc[i][j], 0, 0, 0);
         } else
 #pragma unroll
         for (int kk = 0; kk < KB / 8; ++kk) {
@@ -1002,6 +1066,15 @@ static const TuneEntry* tune_lookup(int kind, int M, int Ca, int Cb, int Ktot, i
     return nullptr;
 }
 
+// Matrix path of the forward-style fast path: 0 = v_mfma_f32_32x32x2_f32, 1 = bf16x3 (see the kernel).  GIM_CONV_PREC sets the
+// start value; gim_conv_precision(mode) switches at run time and returns the previous mode (mode < 0: query only).
+static int g_prec = getenv("GIM_CONV_PREC") ? atoi(getenv("GIM_CONV_PREC")) : 0;
+extern "C" int gim_conv_precision(int mode) {
+    const int prev = g_prec;
+    if (mode == 0 || mode == 1) g_prec = mode;
+    return prev;
+}
+
 extern "C" int gim_conv_tune_override(int tile_cfg, int ksplit, int wgrad_target) {
     g_force_tile = tile_cfg; g_force_ksplit = ksplit; g_wgrad_target = wgrad_target;
     return 0;
@@ -1021,7 +1094,7 @@ static int plan_ksplit(long long wgs, int nk, int tile_area, int table_ks) {
     return ks < 1 ? 1 : (int)ks;
 }
 
-template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int KB>
+template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int KB, int PREC = 0>
 static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
     const int ncls = p.g.pc ? 4 : 1;
@@ -1038,11 +1111,17 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
     p.xcd = (g_xcd && (long long)gx * gy >= 16) ? xcd_mode : 0;
     const dim3 grid = p.xcd == 1 ? dim3(((gx + 7) / 8) * 8 * gy, 1, p.ksplit * ncls)
                     : p.xcd == 2 ? dim3(((gx * gy + 7) / 8) * 8, 1, p.ksplit * ncls) : dim3(gx, gy, p.ksplit * ncls);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB, PREC>), grid, dim3(256), 0, st, p);
 }
 
 template <int BM, int BN, int TM, int TN, int BMODE, int GEN>
 static void launch_cfg(const ConvP& p, size_t y_elems, hipStream_t st) {
+    if constexpr (BMODE == 0 && GEN == 0 && BN >= 32) {
+        if (p.prec == 1) {
+            launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 16, 1>(p, y_elems, st);
+            return;
+        }
+    }
     if constexpr ((GEN & 1) == 0 && BM == 128) {
         if (p.Ca % 32 == 0 && !g_force_kb16) {
             launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 32>(p, y_elems, st);
@@ -1113,6 +1192,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
         p.x_bytes = (unsigned)xb;
     }
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
+    p.prec = g_prec;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
