@@ -100,8 +100,14 @@ def dominant_kernel_roofline(device):
     st = torch.cuda.current_stream().cuda_stream
     flops = 2.0 * N * H * H * Cout * Cin * K * K
     out = {}
+    x3 = lib.gim_conv_precision(-1) == 1
+    dgrad = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
+    if x3:   # the engine's dgrad then runs the k-contiguous kernel on cached transposed weights (ops._conv_dgrad)
+        wt = torch.empty(Cin * K * K * Cout, device=device)
+        lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, K, st)
+        dgrad = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
     for name, fn in (("fwd", lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st)),
-                     ("dgrad", lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)),
+                     ("dgrad", dgrad),
                      ("wgrad", lambda: lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st))):
         for _ in range(3):
             fn()
@@ -114,7 +120,7 @@ def dominant_kernel_roofline(device):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         out[name] = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2)}
-    return {"kernel": "conv_igemm 64->64 3x3 @64x64 x320 img (fp32 MFMA)", "gflop_per_launch": round(flops / 1e9, 2), **out,
+    return {"kernel": "conv_igemm 64->64 3x3 @64x64 x320 img (%s)" % ("fwd / dgrad: bf16x3 split on the bf16 MFMA, wgrad: fp32 MFMA" if x3 else "fp32 MFMA"), "gflop_per_launch": round(flops / 1e9, 2), **out,
             "frac_fwd": round(out["fwd"]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
 
 

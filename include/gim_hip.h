@@ -117,6 +117,14 @@ int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, const int32_t
  * heuristics.  Process-wide, not thread-safe: for tuning runs only. */
 int gim_conv_tune_override(int tile_cfg, int ksplit, int wgrad_target);
 
+/* dgrad on TRANSPOSED weights: the input gradient of gim_conv2d_fwd as gim_conv2d_dgrad computes it (same shape struct, same
+ * fused mask / 1/sigma / folds), but reading WT[Cin][KF][KF][Cout] (gim_conv2d_transpose_weights of the plain or folded
+ * weights), whose rows are k-contiguous for this contraction: dgrad then runs the forward kernel's operand path, bf16x3
+ * included.  Needs Cout % 16 == 0.  (F.conv2d's backward w.r.t. the input, autograd of training/gim_img_training.py:164,176.) */
+int gim_conv2d_transpose_weights(const float* w, float* wt, int Cout, int Cin, int KF, void* stream);
+int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, const float* mask_x, float* dx,
+                       const gim_conv_shape* shape, void* stream);
+
 /* Matrix path of the k-contiguous conv / linear contraction (replaces nothing in the reference: F.conv2d has one fp32 path).
  * 0 = v_mfma_f32_32x32x2_f32; 1 = "bf16x3": every fp32 operand is split exactly into three bf16 numbers and six partial
  * products are accumulated in fp32 on the bf16 matrix pipe - fp32-level accuracy at 2.67x fewer matrix-pipe cycles (layers

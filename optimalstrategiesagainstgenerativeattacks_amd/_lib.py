@@ -63,6 +63,8 @@ SIGNATURES = {
     "gim_colsum2": [P, P, P, P, c_int, c_int, c_int, P],
     "gim_conv_tune_override": [c_int, c_int, c_int],
     "gim_conv_precision": [c_int],
+    "gim_conv2d_transpose_weights": [P, P, c_int, c_int, c_int, P],
+    "gim_conv2d_dgrad_t": [P, P, P, P, P, SP, P],
     "gim_episode_gather": [P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_maxpool_gather": [P, P, P, P, c_int, c_int, c_int, c_float, P],
     "gim_softmax_dim1_bwd_dp": [P, P, P, P, c_int, c_int, c_int, P],

@@ -85,6 +85,7 @@ struct ConvP {
     unsigned x_bytes;   // size of the gathered tensor (buffer-resource range of the fast path)
     int tune_ks;        // host only: split-K factor from the tuning table (0 = heuristic)
     int prec;           // host only: 1 = bf16x3 matrix path where the kernel has one
+    int tune_kind;      // host only: row kind of the launch-tuning table (0 fwd, 1 dgrad k-major, 3 fwd bf16x3, 4 dgrad on transposed weights)
     float pos_inf;      // +infinity as a run-time value
     float pre_slope, mask_slope, out_scale;
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
@@ -143,7 +144,20 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define X3_LDR 28
 
 // 4 consecutive-k floats -> 3 planes x 4 bf16, written as three ds_write_b64 (dst = row base + 2 * k-quad, in dwords)
-__device__ __forceinline__ void x3_split_store(unsigned* dst, const f32x4& x) {
+__device__ __forceinline__ void x3_split_store(unsigned* dst, const f32x4& x, bool is_b = false) {
+#if defined(GIM_DBG_X3_NOSPLIT) || defined(GIM_DBG_X3_NOSPLITB)   // timing experiments: same LDS writes, no split arithmetic
+#ifdef GIM_DBG_X3_NOSPLITB
+    if (is_b)
+#endif
+    {
+        const u32x2 a = {__builtin_bit_cast(unsigned, (float)x[0]), __builtin_bit_cast(unsigned, (float)x[1])};
+        const u32x2 b = {__builtin_bit_cast(unsigned, (float)x[2]), __builtin_bit_cast(unsigned, (float)x[3])};
+        *reinterpret_cast<u32x2*>(dst) = a;
+        *reinterpret_cast<u32x2*>(dst + 8) = b;
+        *reinterpret_cast<u32x2*>(dst + 16) = a;
+        return;
+    }
+#endif
     unsigned r1[4], r2[4], xb[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -294,8 +308,11 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         }
     };
 
-    f32x4 ra[A_ROWS];
-    f32x4 rb0[B_ROWS];
+    // staging registers (global -> VGPR -> LDS).  bf16x3: TWO sets, loads run two K steps ahead of their LDS store (the MFMA
+    // block of a K step is 2.7x shorter than on the fp32 pipe, one step no longer covers the global-load latency)
+    constexpr int NSET = X3 ? 2 : 1;
+    f32x4 raS[NSET][A_ROWS];
+    f32x4 rb0S[NSET][B_ROWS];
     float rb1[B_PER];
     f32x4 rb4[B_PER4];
 
@@ -309,7 +326,10 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         set_tap(k_ta, k_tb);
     };
 
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int k0, auto SETC) {
+        constexpr int S = decltype(SETC)::value;
+        auto& ra = raS[S];
+        auto& rb0 = rb0S[S];
         if constexpr (!GEN) {
             const int ta = k_ta, tb = k_tb, c0 = k_c0;
             const int wtap = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
@@ -420,7 +440,10 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         }
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto SETC) {
+        constexpr int S = decltype(SETC)::value;
+        auto& ra = raS[S];
+        auto& rb0 = rb0S[S];
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             // fused leaky-relu max(x, slope*x) (slope 1 = identity), IN PLACE and branch-free: a conditional copy of the
@@ -436,9 +459,9 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
             for (int i = 0; i < B_ROWS; ++i) {
                 const int row = arow + RP * i;
                 if constexpr (X3) {
-                    if (row < BN) x3_split_store(reinterpret_cast<unsigned*>(Bs) + buf * B_SZ + row * LDA + (aq >> 1), rb0[i]);
+                    if (BN % RP == 0 || row < BN) x3_split_store(reinterpret_cast<unsigned*>(Bs) + buf * B_SZ + row * LDA + (aq >> 1), rb0[i], true);
                 } else {
-                    if (row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
+                    if (BN % RP == 0 || row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
                 }
             }
         } else {
@@ -474,14 +497,27 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
     const int nk_all = (p.Ktot + KB - 1) / KB;
     const int ks0 = kslice * p.kper;
     const int nk = min(nk_all, ks0 + p.kper);
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, NSET - 1>;
     if constexpr (!GEN) seek(ks0 * KB);
-    load_tiles(ks0 * KB);
-    store_tiles(0);
+    load_tiles(ks0 * KB, Set0());
+    store_tiles(0, Set0());
+    if constexpr (X3) {
+        if (ks0 + 1 < nk) load_tiles((ks0 + 1) * KB, Set1());
+    }
     __syncthreads();
-    auto kstep = [&](int ks, auto BUFC) {
+    auto kstep = [&](int ks, auto BUFC, auto MAINC) {
         constexpr int buf = decltype(BUFC)::value;   // compile-time LDS buffer: offsets fold into the ds_read / ds_write immediates
+        // MAIN: a step of the steady-state loop, whose loads and LDS stores are unconditional.  (A load under `if` makes the
+        // number of loads in flight path dependent, and the compiler then waits with the smaller count: vmcnt(2..0) instead
+        // of vmcnt(5..3) in front of the bf16x3 path's store, which drains the loads issued two steps ahead as well.)
+        constexpr bool MAIN = decltype(MAINC)::value;
 #ifndef GIM_DBG_NOLOAD   // timing experiments only (tools/micro/build_dbg.sh): results are wrong with any GIM_DBG_* flag
-        if (ks + 1 < nk) load_tiles((ks + 1) * KB);
+        if constexpr (X3) {
+            if (MAIN || ks + 2 < nk) load_tiles((ks + 2) * KB, std::integral_constant<int, buf>());   // this set's step was stored before the last barrier
+        } else {
+            if (ks + 1 < nk) load_tiles((ks + 1) * KB, Set0());
+        }
 #endif
 #ifndef GIM_NO_IGEMM_FENCE
         __builtin_amdgcn_sched_barrier(0);  // nothing that touches the staged registers may move into the MFMA block
@@ -536,9 +572,9 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
             f32x4 a[TM], b[TN];
 #ifdef GIM_DBG_NOLDS
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ra[i % A_ROWS] + (float)kk;
+            for (int i = 0; i < TM; ++i) a[i] = raS[0][i % A_ROWS] + (float)kk;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = ra[(j + 1) % A_ROWS] - (float)kk;
+            for (int j = 0; j < TN; ++j) b[j] = raS[0][(j + 1) % A_ROWS] - (float)kk;
 #else
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + 32 * i + r) * LDK + 8 * kk + 4 * h]);
@@ -564,15 +600,22 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifndef GIM_DBG_NOSTORE
-        if (ks + 1 < nk) store_tiles(buf ^ 1);
+        if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1, std::integral_constant<int, X3 ? (buf ^ 1) : 0>());
 #endif
 #ifndef GIM_DBG_NOBARRIER
         __syncthreads();
 #endif
     };
-    for (int ks = ks0; ks < nk; ks += 2) {
-        kstep(ks, std::integral_constant<int, 0>());
-        if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>());
+    int ks = ks0;
+    if constexpr (X3) {
+        for (; ks + 3 < nk; ks += 2) {   // steady state: steps ks and ks+1 both have a step two ahead to load
+            kstep(ks, std::integral_constant<int, 0>(), std::true_type());
+            kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
+        }
+    }
+    for (; ks < nk; ks += 2) {
+        kstep(ks, std::integral_constant<int, 0>(), std::false_type());
+        if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>(), std::false_type());
     }
 
     // ---- epilogue: out_scale/sigma, bias, residual, activation mask; logical pixel -> stored pixel ----
@@ -978,6 +1021,34 @@ extern "C" int gim_conv2d_fold_weights(const float* w, float* f, int Cout, int C
 }
 
 // -------------------------------------------------------------------------------------------------
+// transposed weights for the k-contiguous dgrad: WT[ci][a][b][co] = W[co][a][b][ci]  (W plain or folded, T = KF*KF taps)
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int T) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co0 + ty + 8 * r, ci = ci0 + tx;
+        tile[ty + 8 * r][tx] = (co < Cout && ci < Cin) ? w[((long long)co * T + tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + ty + 8 * r, co = co0 + tx;
+        if (ci < Cin && co < Cout) wt[((long long)ci * T + tap) * Cout + co] = tile[tx][ty + 8 * r];
+    }
+}
+
+extern "C" int gim_conv2d_transpose_weights(const float* w, float* wt, int Cout, int Cin, int KF, void* stream) {
+    GIM_CHECK_ARG(w && wt && Cout > 0 && Cin > 0 && KF > 0 && KF * KF <= 65535, "transpose_weights: bad args");
+    hipLaunchKernelGGL(transpose_weights_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, KF * KF), dim3(256), 0, (hipStream_t)stream,
+                       w, wt, Cout, Cin, KF * KF);
+    return gim_check_launch("gim_conv2d_transpose_weights");
+}
+
+// -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
 static int check_shape(const gim_conv_shape* s) {
@@ -1137,7 +1208,7 @@ static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     const int M = p.M, Cb = p.Cb;
     const int force_tile = g_force_tile;
     ConvP pt = p;
-    const TuneEntry* te = (force_tile || g_force_ksplit) ? nullptr : tune_lookup(BMODE, M, p.Ca, Cb, p.Ktot, p.g.pc);
+    const TuneEntry* te = (force_tile || g_force_ksplit) ? nullptr : tune_lookup(p.tune_kind, M, p.Ca, Cb, p.Ktot, p.g.pc);
     pt.tune_ks = te ? te->ks : 0;
     const int table_tile = te ? te->tile : 0;
     static const int big_cfg = getenv("GIM_CONV_BIG") ? atoi(getenv("GIM_CONV_BIG")) : 641;       // experiments
@@ -1193,6 +1264,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     }
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
     p.prec = g_prec;
+    p.tune_kind = g_prec == 1 ? 3 : 0;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
@@ -1201,8 +1273,8 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     return gim_check_launch("gim_conv2d_fwd");
 }
 
-extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
-                                const gim_conv_shape* s, void* stream) {
+static int dgrad_impl(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
+                      const gim_conv_shape* s, void* stream, bool transposed) {
     int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(dy && w && dx, "conv dgrad: null pointer");
@@ -1214,9 +1286,9 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
         if (s->N > 1 && (xi > yi ? xi : yi) * s->N * sizeof(float) > BUF_MAX_BYTES) {
             gim_conv_shape a = *s, b = *s;
             a.N = s->N / 2; b.N = s->N - a.N;
-            rc = gim_conv2d_dgrad(dy, w, sigma, mask_x, dx, &a, stream);
+            rc = dgrad_impl(dy, w, sigma, mask_x, dx, &a, stream, transposed);
             if (rc) return rc;
-            return gim_conv2d_dgrad(dy + a.N * yi, w, sigma, mask_x ? mask_x + a.N * xi : nullptr, dx + a.N * xi, &b, stream);
+            return dgrad_impl(dy + a.N * yi, w, sigma, mask_x ? mask_x + a.N * xi : nullptr, dx + a.N * xi, &b, stream, transposed);
         }
     }
     ConvP p{};
@@ -1239,9 +1311,29 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
     const bool gen = (s->Cout % BK) != 0 || ((uintptr_t)dy & 15);
     const bool bscalar = (s->Cin % 4) != 0 || ((uintptr_t)w & 15);
     hipStream_t st = (hipStream_t)stream;
+    p.tune_kind = 1;
+    if (transposed) {
+        // WT[ci][a][b][co]: the weight rows are k-contiguous (k = (tap, co)), i.e. the forward kernel's operand layout
+        GIM_CHECK_ARG(!gen && !((uintptr_t)w & 15), "conv dgrad (transposed weights): Cout % 16 == 0 and 16-byte aligned operands required");
+        p.Cin_w = s->Cout;
+        p.prec = g_prec;
+        p.tune_kind = 4;
+        launch_igemm<0, 0>(p, y_elems, st);
+        return gim_check_launch("gim_conv2d_dgrad_t");
+    }
     if (gen) { if (bscalar) launch_igemm<1, 3>(p, y_elems, st); else launch_igemm<1, 1>(p, y_elems, st); }
     else     { if (bscalar) launch_igemm<1, 2>(p, y_elems, st); else launch_igemm<1, 0>(p, y_elems, st); }
     return gim_check_launch("gim_conv2d_dgrad");
+}
+
+extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
+                                const gim_conv_shape* s, void* stream) {
+    return dgrad_impl(dy, w, sigma, mask_x, dx, s, stream, false);
+}
+
+extern "C" int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, const float* mask_x, float* dx,
+                                  const gim_conv_shape* s, void* stream) {
+    return dgrad_impl(dy, wt, sigma, mask_x, dx, s, stream, true);
 }
 
 // wgrad roles.  plain: A = dy [N,H,W,Cout], B = gathered x.  pool: A = dy [N,H/2,W/2,Cout], B = x gathered with

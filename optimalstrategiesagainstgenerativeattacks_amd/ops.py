@@ -7,6 +7,7 @@ must be CUDA(HIP) float32.  Activations are NHWC.
 import collections
 import ctypes
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -317,7 +318,7 @@ class ConvFn(Function):
         dev = dy.device
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, ctx.cfg, st)
+            dx = _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, ctx.cfg, st, w)
         want_w = ctx.needs_input_grad[1]
         want_b = has_bias and ctx.needs_input_grad[2]
         Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
@@ -336,12 +337,40 @@ class ConvFn(Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
-def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st):
-    """dx = lrelu'(x) * dgrad(dy, w) / sigma  (through the pool / sub-pixel folds when the forward used them)."""
+_WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
+
+
+def _transposed(lib, w, wk, Cout, Cin, KF):
+    """WT[Cin][KF][KF][Cout] of the (plain or folded) weights `wk` of parameter `w`, recomputed only when the weights
+    changed (autograd version counter for torch-side writes, optim.weights_epoch for the fused Adam kernel)."""
+    from . import optim
+    key = (w._version, optim.weights_epoch(w))
+    slot = (w.data_ptr(), KF)
+    ent = _WT_CACHE.get(slot)
+    cur = torch.cuda.current_stream()
+    if ent is None or ent[0] != key or ent[4]() is not w:
+        wt = torch.empty(Cin * KF * KF * Cout, device=wk.device, dtype=torch.float32)
+        check(lib.gim_conv2d_transpose_weights(_p(wk), _p(wt), Cout, Cin, KF, cur.cuda_stream), "transpose_weights")
+        ent = (key, wt, cur.record_event(), cur, weakref.ref(w, lambda _r, slot=slot: _WT_CACHE.pop(slot, None)))
+        _WT_CACHE[slot] = ent
+    elif ent[3] != cur:
+        cur.wait_event(ent[2])
+        ent[1].record_stream(cur)
+    return ent[1]
+
+
+def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
+    """dx = lrelu'(x) * dgrad(dy, w) / sigma  (through the pool / sub-pixel folds when the forward used them).
+    With the bf16x3 matrix path selected (gim_conv_precision) and the parameter `w` given, layers with Cout % 16 == 0 run
+    the k-contiguous kernel on cached transposed weights (gim_conv2d_dgrad_t)."""
     N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
     mask = x if pre_slope != 1.0 else None
     dx = torch.empty_like(x)
     wk = wf if fold else wp
+    if w is not None and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold) and lib.gim_conv_precision(-1) == 1:
+        wt = _transposed(lib, w, wk, Cout, Cin, KH + 1 if fold else KH)
+        check(lib.gim_conv2d_dgrad_t(_p(dy), _p(wt), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad_t")
+        return dx
     if ups and not fold:
         dxu = torch.empty((N, H, W, Cin), device=dy.device, dtype=torch.float32)
         check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), None, _p(dxu), sh, st), "conv2d_dgrad")
@@ -422,7 +451,7 @@ class ConvDgradFn(Function):
         lib = _lib.load()
         N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
         sh = _shape(N, H, W, Cin, Cout, KH, 0, pre_slope, 1 if pool else 0, fold, 0)
-        dx = _conv_dgrad(lib, dy, x, weight_phys(w), wf, sigma, sh, cfg, _stream())
+        dx = _conv_dgrad(lib, dy, x, weight_phys(w), wf, sigma, sh, cfg, _stream(), w)
         ctx.save_for_backward(dy, w, x, sigma, u_s, v_s, wf)
         ctx.cfg = cfg
         return dx

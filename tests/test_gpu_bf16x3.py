@@ -1,0 +1,86 @@
+"""GPU parity of the bf16x3 matrix path (gim_conv_precision(1)): the forward-style contraction and - through cached
+transposed weights, gim_conv2d_dgrad_t - the input gradient run on the bf16 matrix pipe with every fp32 operand split exactly
+into three bf16 numbers.  The SAME checks and the SAME tolerances as the fp32-MFMA path (operators 3e-5 against fp64, losses /
+logits 1e-3 against the reference goldens): the tests of test_gpu_ops.py / test_gpu_models.py are re-run with the path switched on.
+(Running the whole GPU suite with GIM_CONV_PREC=1 does the same for every test.)"""
+import pytest
+import torch
+
+from tests import test_gpu_models as tm
+from tests import test_gpu_ops as to
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16x3():
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    lib = _lib.load()
+    prev = lib.gim_conv_precision(1)
+    assert lib.gim_conv_precision(-1) == 1
+    yield lib
+    lib.gim_conv_precision(prev)
+
+
+FAST = [c for c in to.CONV_CASES if c[1] % 16 == 0]          # the k-contiguous fast path (Cin % 16 == 0)
+POOL_FAST = [c for c in to.POOL_CASES if c[1] % 16 == 0]
+
+
+@pytest.mark.parametrize("case", FAST, ids=[str(c) for c in FAST])
+def test_conv2d_fwd_bwd_bf16x3(bf16x3, case):
+    to.test_conv2d_fwd_bwd(case)
+
+
+@pytest.mark.parametrize("case", POOL_FAST, ids=[str(c) for c in POOL_FAST])
+def test_conv2d_pool_fold_bf16x3(bf16x3, case):
+    to.test_conv2d_pool_fold(case)
+
+
+def test_linear_bf16x3(bf16x3):
+    to.test_linear_fwd_bwd()
+
+
+@pytest.mark.parametrize("N,Cin,Cout,K,H,pool,ups", [(3, 64, 128, 3, 16, 0, 0), (2, 128, 64, 3, 16, 1, 0), (2, 64, 64, 3, 16, 0, 1),
+                                                    (5, 32, 48, 9, 8, 0, 0)])
+def test_dgrad_on_transposed_weights_equals_dgrad(bf16x3, N, Cin, Cout, K, H, pool, ups):
+    """gim_conv2d_dgrad_t (k-contiguous kernel on WT[Cin][KF][KF][Cout], bf16x3) against gim_conv2d_dgrad (k-major weights, fp32
+    MFMA) through the C ABI, plain / pool-fold / sub-pixel geometries, with the fused mask and 1/sigma."""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    lib = bf16x3
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    fold = 1 if (pool or ups) else 0
+    KF = K + 1 if fold else K
+    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, 0.2, pool, fold, 0)
+    w = torch.randn(Cout, KF, KF, Cin, device=dev, generator=g) * 0.05
+    dy = torch.randn(N, H >> pool, H >> pool, Cout, device=dev, generator=g)
+    lo = 1 if (ups and fold) else 0
+    x = torch.randn(N, H >> lo, H >> lo, Cin, device=dev, generator=g)
+    sigma = torch.tensor([1.3], device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    d0, d1 = torch.empty_like(x), torch.empty_like(x)
+    wt = torch.empty(Cin * KF * KF * Cout, device=dev)
+    _lib.check(lib.gim_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), sigma.data_ptr(), x.data_ptr(), d0.data_ptr(), sh, st), "dgrad")
+    _lib.check(lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st), "transpose")
+    assert torch.equal(wt.view(Cin, KF, KF, Cout), w.permute(3, 1, 2, 0).contiguous())
+    _lib.check(lib.gim_conv2d_dgrad_t(dy.data_ptr(), wt.data_ptr(), sigma.data_ptr(), x.data_ptr(), d1.data_ptr(), sh, st), "dgrad_t")
+    err = float((d0 - d1).abs().max() / d0.abs().max())
+    assert err < 2e-6, err
+    # Cout not a multiple of 16 is refused, not mis-computed
+    bad = _lib.GimConvShape(N, H, H, Cin, 24, K, 0, 0.2, 0, 0, 0)
+    assert lib.gim_conv2d_dgrad_t(dy.data_ptr(), wt.data_ptr(), None, None, d1.data_ptr(), bad, st) != 0
+
+
+def test_transposed_weight_cache_follows_the_optimizer(bf16x3):
+    """ops._transposed caches WT per parameter and recomputes it after a FusedAdam update (weights_epoch) - three protocol
+    iterations against the reference golden would drift otherwise."""
+    tm.test_trainer_protocol_vs_reference_golden("reg0")
+
+
+def test_whole_nets_bf16x3(bf16x3):
+    tm.test_tiny_nets_vs_reference_golden()
+    tm.test_voxceleb_shape_vs_reference_golden()
+
+
+def test_r1_second_order_bf16x3(bf16x3):
+    tm.test_product_vs_oracle_fp32_step_and_state(10.0)

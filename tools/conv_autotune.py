@@ -99,11 +99,20 @@ def main():
         cols = KF * KF * (Cout if up_fold else Cin)
         Mw = N * (H >> (1 if fold else 0)) * (W >> (1 if fold else 0))
         keys["wgrad"] = (2, Mw, rows, cols, KH, (1 if pool else 0) + (2 if up_fold else 0))
+        x3 = lib.gim_conv_precision(-1) == 1      # bf16x3 matrix path: its own table rows (kinds 3, 4)
+        dgrad_fn = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
+        if x3:
+            keys["fwd"] = (3,) + keys["fwd"][1:]
+            if Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
+                wt = torch.empty(Cin * KF * KF * Cout, device=dev)
+                lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
+                keys["dgrad"] = (4,) + keys["dgrad"][1:]
+                dgrad_fn = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
         runs = {"fwd": (cnt, lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st)),
-                "dgrad": (n_dx, lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)),
+                "dgrad": (n_dx, dgrad_fn),
                 "wgrad": (n_dw, lambda: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh, st))}
         for kind, (calls, fn) in runs.items():
-            if not calls:
+            if not calls or (x3 and (kind == "wgrad" or keys[kind][0] < 3)):   # bf16x3 pass: only its own rows (kinds 3, 4)
                 continue
             Cb = keys[kind][3]
             lib.gim_conv_tune_override(0, 0, 0)

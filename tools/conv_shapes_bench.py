@@ -81,7 +81,12 @@ def main():
         foldmode = (2 if ups else 1) if fold else 0
         flops = 2.0 * N * H * W * Cout * Cin * KH * KH
         t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
-        t_d = time_ms(lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
+        if lib.gim_conv_precision(-1) == 1 and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
+            wt = torch.empty(Cin * KF * KF * Cout, device=dev)
+            lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
+            t_d = time_ms(lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
+        else:
+            t_d = time_ms(lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
 
         def wg():
             lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st)
