@@ -60,7 +60,7 @@ def measured_hbm_traffic(workload, B):
     """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE; profiles/*hbm_traffic*.json).  bench.py cannot run the profiler on itself, so this
     is the last profiled value for the workload, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic_%s_B%d.json" % (workload, B))
+    path = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic_%s_B%d.json" % (workload, B))
     try:
         with open(path) as f:
             return float(json.load(f)["hbm_bytes_per_step"])
@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="episodes per GPU (default: 16 for vox64, 32 for om32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
+    ap.add_argument("--no-bf16x3", action="store_true", help="skip the informational second measurement on the bf16x3 matrix path")
     ap.add_argument("--reg-param", type=float, default=0.0, help="R1 weight (BASELINE's metric is quoted at 0; 10 = the paper's VoxCeleb2 setting)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     args = ap.parse_args()
@@ -211,28 +212,47 @@ def main():
 
     import warnings
     warnings.filterwarnings("ignore")
-    log("models built; warm-up")
-    for i in range(args.warmup):
-        out = step()
-        torch.cuda.synchronize()
-        log("warm-up step %d done" % i)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.time()
-    ev0.record()
-    for _ in range(args.steps):
-        out = step()
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib as _glib
     from optimalstrategiesagainstgenerativeattacks_amd import ops as _ops
-    _ops.join_lanes()   # the last discriminator step runs on its own stream: ev1 must come after it
-    ev1.record()
-    fence()
-    dt = time.time() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    log("timed region done: %.3f s for %d steps" % (dt, args.steps))
-    if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+
+    def timed(label):
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize; (seconds [max over ranks], device ms, last out)."""
+        for i in range(args.warmup):
+            out = step()
+            torch.cuda.synchronize()
+            log("%s: warm-up step %d done" % (label, i))
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.time()
+        ev0.record()
+        for _ in range(args.steps):
+            out = step()
+        _ops.join_lanes()   # the last discriminator step runs on its own stream: ev1 must come after it
+        ev1.record()
+        fence()
+        dt = time.time() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        log("%s: timed region done: %.3f s for %d steps" % (label, dt, args.steps))
+        if world > 1:
+            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, dev_ms, out
+
+    log("models built; warm-up")
+    matrix_path = "bf16x3" if _glib.load().gim_conv_precision(-1) == 1 else "fp32 MFMA"
+    dt, dev_ms, out = timed(matrix_path)
+    # Informational second measurement, never `value`: the same K steps with the forward / dgrad contractions on the bf16
+    # matrix pipe by exact 3-way operand splitting (gim_conv_precision(1): fp32-level error, tests/test_gpu_bf16x3.py)
+    x3 = None
+    if matrix_path == "fp32 MFMA" and not args.no_bf16x3 and graphed is None and world == 1:
+        _glib.load().gim_conv_precision(1)
+        dt3, _, _ = timed("bf16x3")
+        _glib.load().gim_conv_precision(0)
+        x3 = {"value": round(B * world * args.steps / dt3, 3), "unit": "episodes/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+              "what": "same workload and steps with gim_conv_precision(1): conv / linear forward and dgrad on the bf16 MFMA with every "
+                      "fp32 operand split exactly into three bf16 (6 partial products, fp32 accumulate; error vs fp64 equal to the fp32 "
+                      "MFMA's: tools/micro/bf16x3_gemm.hip, same parity tolerances: tests/test_gpu_bf16x3.py); wgrad stays on the fp32 MFMA"}
     g_loss, d_loss = float(out[0][0]), float(out[1][0])
 
     if rank == 0:
@@ -247,13 +267,15 @@ def main():
             "config": {"workload": "%s: %dx%dx%d synthetic episodes, m=%d n=%d k=%d, %d episodes/GPU, style_dim=512, "
                                    "G step + D step + 2 Adam updates per step, reg_param=%g" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B, args.reg_param),
                        "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world,
-                       "launch": "hipGraph replay" if args.graph else "eager"},
+                       "launch": "hipGraph replay" if args.graph else "eager", "matrix_path": matrix_path},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": measured_hbm_traffic(args.workload, B) if world == 1 else None, "traffic_unit": "HBM bytes/step (rocprofv3 PMC, profiles/)",
                          "algo_gflop_per_episode": round(algo, 1), "device_ms_per_step": round(dev_ms / args.steps, 3)},
             "final_losses": {"g": round(g_loss, 5), "d": round(d_loss, 5)},
         }
+        if x3 is not None:
+            line["bf16x3_path"] = x3
         if not args.no_kernel_bench:
             line["dominant_kernel"] = dominant_kernel_roofline(device)
             log("kernel microbenchmark done")

@@ -11,8 +11,10 @@ python bench.py --workload om32 --no-cpu-baseline --no-kernel-bench > $out/bench
 python bench.py --batch 64 --no-cpu-baseline --no-kernel-bench > $out/bench_vox64_B64.log 2>&1 || exit 1
 python bench.py --reg-param 10 --no-cpu-baseline --no-kernel-bench > $out/bench_vox64_B16_r1.log 2>&1 || exit 1
 python bench.py --graph --no-cpu-baseline --no-kernel-bench > $out/bench_vox64_B16_graph.log 2>&1 || exit 1
+python bench.py --workload vox128 --no-cpu-baseline --no-kernel-bench > $out/bench_vox128_B2.log 2>&1 || exit 1
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 GIM_FORCE_ALLREDUCE=1 python bench.py --no-cpu-baseline --no-kernel-bench > $out/bench_vox64_B16_rccl1rank.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/stats.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-bench > $out/pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-bench > $out/pmc_write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x3 > $out/stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-bench --no-bf16x3 > $out/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-bench --no-bf16x3 > $out/pmc_write.log 2>&1 || exit 1
 echo measured
