@@ -84,3 +84,43 @@ def test_whole_nets_bf16x3(bf16x3):
 
 def test_r1_second_order_bf16x3(bf16x3):
     tm.test_product_vs_oracle_fp32_step_and_state(10.0)
+
+
+def test_loss_curve_vs_oracle():
+    """north_star: "loss curves matching reference within 1e-3".  Six consecutive training iterations (generator step +
+    discriminator step + both Adam updates, fresh episodes and latent noise each iteration) on the tiny config from a
+    conditioned state: every generator / discriminator loss of the product - on the fp32 MFMA and on the bf16x3 path - against
+    the oracle's fp64 run of the same protocol.  The game amplifies rounding differences ~4x per iteration (beta1 = 0 Adam moves
+    every weight by +-lr whatever the gradient's size): the reference's own fp32 arithmetic (the oracle run in fp32 on the CPU)
+    leaves the fp64 curve by 1e-3 after ~9 iterations, and so does every fp32 implementation
+    (tools/loss_curve_probe.py, profiles/r01_k_loss_curve_deviation.txt: 16 iterations, oracle fp32 / fp32 MFMA / bf16x3 side by
+    side); six iterations leave a 25x margin below 1e-3 on both matrix paths."""
+    import tempfile
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    from oracle import gim_oracle as go
+    from tests.helpers import episode, filled_sd, load_keys, relerr
+    from tests.test_gpu_models import _product_models, dev
+    lib = _lib.load()
+    prev = lib.gim_conv_precision(-1)
+    try:
+        tag, cfg = "curve", "16_1_32"
+        B, m, n, k, c, s, d = 4, 1, 3, 4, 1, 16, 32
+        keys = load_keys(cfg)
+        otr = go.OracleTrainer(filled_sd(keys["au"], tag + "/au/"), filled_sd(keys["im"], tag + "/im/"), n, 1e-4, 1e-4, 1e-6)
+        prods = []
+        for mode in (0, 1):
+            au, im = _product_models(tag, cfg)
+            with tempfile.TemporaryDirectory() as td:
+                tr = G.GIMImgTrainer(td, m, n, k, au, im, 1e-4, 1e-4, 1e-6, reg_param=0.0)
+            prods.append((mode, G.DataParallelMock(tr)))
+        for it in range(6):
+            leaked, real, si, z = episode("%s%d" % (tag, it), B, m, n, k, c, s, d)
+            g_o, d_o = otr.step(leaked, real, si, z)
+            for mode, trainer in prods:
+                lib.gim_conv_precision(mode)
+                gi, di = G.gim_step(trainer, *[t.float().to(dev()) for t in (leaked, real, si)], z=z.float().to(dev()))
+                eg, ed = relerr(gi[0], g_o[0].mean()), relerr(di[0], d_o[0].mean())
+                assert eg < 1e-3 and ed < 1e-3, (("fp32 MFMA", "bf16x3")[mode], it, eg, ed)
+    finally:
+        lib.gim_conv_precision(prev)
