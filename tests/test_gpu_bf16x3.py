@@ -93,8 +93,8 @@ def test_loss_curve_vs_oracle():
     the oracle's fp64 run of the same protocol.  The game amplifies rounding differences ~4x per iteration (beta1 = 0 Adam moves
     every weight by +-lr whatever the gradient's size): the reference's own fp32 arithmetic (the oracle run in fp32 on the CPU)
     leaves the fp64 curve by 1e-3 after ~9 iterations, and so does every fp32 implementation
-    (tools/loss_curve_probe.py, profiles/r01_k_loss_curve_deviation.txt: 16 iterations, oracle fp32 / fp32 MFMA / bf16x3 side by
-    side); six iterations leave a 25x margin below 1e-3 on both matrix paths."""
+    (tools/loss_curve_probe.py, profiles/r01_k_loss_curve_deviation.txt: oracle fp32 / fp32 MFMA / bf16x3 side by side; both
+    matrix paths stay at 1e-7 for seven iterations, the CPU fp32 run is at 1e-4 by then); six iterations leave a wide margin."""
     import tempfile
     import optimalstrategiesagainstgenerativeattacks_amd as G
     from optimalstrategiesagainstgenerativeattacks_amd import _lib
