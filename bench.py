@@ -225,11 +225,17 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.time()
         ev0.record()
+        marks = []
         for _ in range(args.steps):
             out = step()
+            if os.environ.get("GIM_BENCH_STEP_EVENTS"):   # diagnostics: where the caller's stream stands after every step
+                marks.append(torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)))
         _ops.join_lanes()   # the last discriminator step runs on its own stream: ev1 must come after it
         ev1.record()
         fence()
+        if marks:
+            ts = [ev0.elapsed_time(m) for m in marks]
+            log("%s: per-step ms on the caller's stream: %s" % (label, " ".join("%.1f" % (b - a) for a, b in zip([0.0] + ts[:-1], ts))))
         dt = time.time() - t0
         dev_ms = ev0.elapsed_time(ev1)
         log("%s: timed region done: %.3f s for %d steps" % (label, dt, args.steps))

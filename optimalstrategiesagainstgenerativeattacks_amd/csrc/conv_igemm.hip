@@ -771,16 +771,62 @@ struct WgP {
 // bases); VEC = 1: scalar fallback (3- and 6-channel image layers, 1-channel Omniglot).
 // Workgroups of the first column tile also produce the bias gradient sum_m dY[m][co] of their pixel slice from
 // the dY values they stream anyway (bias_slabs[slice][Cout]).
-template <int BM, int BN, int TM, int TN, int VEC, bool FASTB>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
+// PREC 1 (bf16x3, see conv_igemm_kernel): the K dimension of this contraction is the PIXEL index, which is not contiguous for a
+// fixed channel in either NHWC operand.  The tiles stay k-major in LDS - three bf16 planes [k][channel], written without any
+// transposition (a thread's float4 = 4 channels of one pixel -> one ds_write_b64 per plane) - and the MFMA operands (8 consecutive
+// k of one channel per lane) come out of gfx950's transposing LDS read ds_read_b64_tr_b16: per 16-lane group a block of 4 k-rows x
+// 16 channels, lane 4q+p supplying the address of row q / channels 4p..4p+3, lane i receiving channel i's four k values.  Rows
+// are padded to a stride = 64 (mod 128) bytes: the 4 rows of a block then sit 16 banks apart (conflict-free, 32-lane halves).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 lds_tr_bf16x8(const char* base, int off_lo, int off_hi) {
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off_hi));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// 4 channels of one pixel -> three planes x 4 bf16 (dst = byte address of the quad in plane 0, plane stride in bytes)
+__device__ __forceinline__ void x3_split_store_planes(char* dst, int plane_bytes, const float (&x)[4]) {
+    unsigned r1[4], r2[4], xb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xb[e] = __builtin_bit_cast(unsigned, x[e]);
+        const float d1 = x[e] - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);
+        r1[e] = __builtin_bit_cast(unsigned, d1);
+        const float d2 = d1 - __builtin_bit_cast(float, r1[e] & 0xFFFF0000u);
+        r2[e] = __builtin_bit_cast(unsigned, d2);
+    }
+    const u32x2 hi = {__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
+    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    *reinterpret_cast<u32x2*>(dst) = hi;
+    *reinterpret_cast<u32x2*>(dst + plane_bytes) = mid;
+    *reinterpret_cast<u32x2*>(dst + 2 * plane_bytes) = lo;
+}
+
+template <int BM, int BN, int TM, int TN, int VEC, bool FASTB, int PREC = 0>
+#ifndef GIM_X3_WG_OCC
+#define GIM_X3_WG_OCC 2
+#endif
+#ifndef GIM_X3_WG_LDSPAD
+#define GIM_X3_WG_LDSPAD 0     // experiments: extra LDS bytes per workgroup (caps how many share a CU)
+#endif
+__global__ __launch_bounds__(256, PREC ? GIM_X3_WG_OCC : 1) void conv_wgrad_kernel(const WgP p) {
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr bool X3 = PREC == 1;
+    static_assert(!X3 || VEC == 4, "bf16x3 wgrad: vector path only");
     constexpr int AU = BM / VEC, BU = BN / VEC;                 // load units per tile row
     constexpr int A_RSTEP = 256 / AU, B_RSTEP = 256 / BU;       // tile rows covered per pass
     constexpr int A_PER = (BK + A_RSTEP - 1) / A_RSTEP, B_PER = (BK + B_RSTEP - 1) / B_RSTEP;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    // bf16x3 image: bytes per k-row (stride = 64 mod 128), per plane, per buffer
+    constexpr int RSA = ((BM * 2) % 128 == 64) ? BM * 2 : BM * 2 + 64, RSB = ((BN * 2) % 128 == 64) ? BN * 2 : BN * 2 + 64;
+    constexpr int PLA = BK * RSA, PLB = BK * RSB;
+    constexpr int A_FLOATS = X3 ? 3 * PLA / 4 : BK * BM, B_FLOATS = X3 ? 3 * PLB / 4 : BK * BN;
+    static_assert(!X3 || 2 * A_FLOATS >= 256 * VEC, "bias reduction scratch");
+    __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS + (X3 ? GIM_X3_WG_LDSPAD / 8 : 0)];
 
     const Geo& g = p.g;
     const int t = threadIdx.x;
@@ -912,6 +958,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) rb[i][e] = __builtin_amdgcn_fmed3f(rb[i][e], rb[i][e] * p.pre_slope, p.pos_inf);
         }
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int row = ak + i * A_RSTEP;
+                if (A_RSTEP * A_PER == BK || row < BK) x3_split_store_planes(reinterpret_cast<char*>(&As[buf][0]) + row * RSA + ac * 2, PLA, ra[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int row = bk + i * B_RSTEP;
+                if (B_RSTEP * B_PER == BK || row < BK) x3_split_store_planes(reinterpret_cast<char*>(&Bs[buf][0]) + row * RSB + bc * 2, PLB, rb[i]);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int row = ak + i * A_RSTEP;
@@ -947,6 +1006,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+    f32x16 acc2[X3 ? TM : 1][X3 ? TN : 1];   // bf16x3: the five small partial products (see conv_igemm_kernel)
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[i][jj][e] = 0.f;
+    }
+    // transposed-read lane offsets: k-row 8h + q, channels (wave base) + 16 * (lane bit 4) + 4p  (bytes)
+    const int tr_q = (lane >> 2) & 3, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
+    const int tr_a = (8 * h + tr_q) * RSA + (wm0 + 16 * tr_g + 4 * tr_p) * 2;
+    const int tr_b = (8 * h + tr_q) * RSB + (wn0 + 16 * tr_g + 4 * tr_p) * 2;
 
     const int nk = (mend > mbeg) ? (mend - mbeg + BK - 1) / BK : 0;
     if (nk > 0) {
@@ -958,6 +1030,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         const int buf = ks & 1;
         if (ks + 1 < nk) load_tiles(mbeg + (ks + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);  // keep every consumer of the staged registers behind the MFMA block
+        if constexpr (X3) {
+            const char* Ab = reinterpret_cast<const char*>(&As[buf][0]) + tr_a;
+            const char* Bb = reinterpret_cast<const char*>(&Bs[buf][0]) + tr_b;
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i][pl] = lds_tr_bf16x8(Ab, pl * PLA + 64 * i, pl * PLA + 64 * i + 4 * RSA);
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) b[jj][pl] = lds_tr_bf16x8(Bb, pl * PLB + 64 * jj, pl * PLB + 64 * jj + 4 * RSB);
+            }
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // (plane of A, plane of B), small terms first
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        if (q < 5) acc2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[jj][TB[q]], acc2[i][jj], 0, 0, 0);
+                        else acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[jj][TB[q]], acc[i][jj], 0, 0, 0);
+                    }
+        } else
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             float a[TM], b[TN];
@@ -976,6 +1070,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         __syncthreads();
     }
 
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) acc[i][jj] += acc2[i][jj];
+    }
     // each accumulator register is two 128-byte row segments per wave: the shape float atomics run at full rate for
     float* out = p.slabs + (p.atomic ? 0 : (long long)blockIdx.z * p.Cout * p.Kcols);
 #pragma unroll
@@ -1373,6 +1473,12 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     q.M = (int)M;
     q.bm = q.rows > 64 ? 128 : (q.rows > 32 ? 64 : 32);
     q.bn = (q.bm == 32) ? 128 : (q.cols > 64 ? 128 : 64);
+    if (g_prec == 1) {   // bf16x3 tiles carry 1.9x the LDS of the fp32 ones: caps for experiments (GIM_X3_WG_BM / GIM_X3_WG_BN)
+        static const int cap_m = getenv("GIM_X3_WG_BM") ? atoi(getenv("GIM_X3_WG_BM")) : 128;
+        static const int cap_n = getenv("GIM_X3_WG_BN") ? atoi(getenv("GIM_X3_WG_BN")) : 128;
+        if (q.bm > cap_m && q.bm > 32) q.bm = cap_m;
+        if (q.bn > cap_n && q.bm != 32) q.bn = cap_n;
+    }
     const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
     // about two workgroups per CU in total, and at least 32 K-steps (512 pixels) per workgroup so that the
     // slab write + later slab reduction stay small next to the MFMA work
@@ -1401,6 +1507,15 @@ static const bool g_wgrad_atomic = getenv("GIM_WGRAD_SLABS") == nullptr;
 extern "C" int gim_conv2d_wgrad_slabs(const gim_conv_shape* s) {
     if (check_shape(s)) return GIM_E_BADARG;
     return g_wgrad_atomic ? 1 : wgrad_plan(s).ns;
+}
+
+template <bool FASTB>
+static void launch_wgrad_x3(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, 4, FASTB, 1>), g, dim3(256), 0, st, p);
 }
 
 template <int VEC, bool FASTB>
@@ -1449,7 +1564,12 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     dim3 g((q.cols + q.bn - 1) / q.bn, (q.rows + q.bm - 1) / q.bm, q.ns);
     const bool vec = (s->Cin % 4 == 0) && (s->Cout % 4 == 0) && !(((uintptr_t)dy | (uintptr_t)x) & 15);
     const bool fastb = vec && p.g.ups == 0 && ((p.g.H * p.g.W) & (BK - 1)) == 0;   // a K step stays inside one image
-    if (fastb) launch_wgrad<4, true>(p, q.bm, q.bn, g, (hipStream_t)stream);
+    static const bool x3_wgrad = getenv("GIM_X3_NO_WGRAD") == nullptr;   // A/B switch
+    if (g_prec == 1 && vec && x3_wgrad) {
+        if (fastb) launch_wgrad_x3<true>(p, q.bm, q.bn, g, (hipStream_t)stream);
+        else launch_wgrad_x3<false>(p, q.bm, q.bn, g, (hipStream_t)stream);
+    }
+    else if (fastb) launch_wgrad<4, true>(p, q.bm, q.bn, g, (hipStream_t)stream);
     else if (vec) launch_wgrad<4, false>(p, q.bm, q.bn, g, (hipStream_t)stream);
     else launch_wgrad<1, false>(p, q.bm, q.bn, g, (hipStream_t)stream);
     return gim_check_launch("gim_conv2d_wgrad");

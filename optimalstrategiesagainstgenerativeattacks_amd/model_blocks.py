@@ -118,12 +118,13 @@ class SNConv2d(nn.Module):
         from . import optim
         w = self.weight_orig
         key = (w.data_ptr(), w._version, optim.weights_epoch(w))
+        raw = ops._stream()   # raw handle: building a torch Stream object per call costs microseconds of host time
         if self._fold_cache[0] != key:
             with torch.no_grad():
                 f = ops._folded(ops.weight_phys(w), self.out_channels, self.in_channels, self.kernel_size)
             # other streams (one per encoder pass) reuse F: they wait for the kernel that wrote it
-            self._fold_cache = (key, f, torch.cuda.current_stream().record_event(), torch.cuda.current_stream())
-        elif self._fold_cache[3] != torch.cuda.current_stream():
+            self._fold_cache = (key, f, torch.cuda.current_stream().record_event(), raw)
+        elif self._fold_cache[3] != raw:
             torch.cuda.current_stream().wait_event(self._fold_cache[2])
         return self._fold_cache[1]
 
