@@ -1245,7 +1245,8 @@ static const bool g_use_table = getenv("GIM_CONV_NO_TABLE") == nullptr;
 static const bool g_no_n16 = getenv("GIM_CONV_NO_N16") != nullptr;   // A/B switch
 
 // Launch configurations measured per layer shape on an MI355X (tools/conv_autotune.py writes conv_tune_table.inc):
-// {kind (0 fwd-style, 1 dgrad-style, 2 wgrad), M, Ca, Cb, Ktot, parity classes, tile config, split-K | wgrad slice target}.
+// {kind (0 fwd-style, 1 dgrad-style, 2 wgrad; bf16x3 path: 3 fwd, 4 dgrad on transposed weights, 5 wgrad), M, Ca, Cb, Ktot, parity classes,
+//  tile config, split-K | wgrad slice target}.
 // Shapes that are not in the table use the heuristics below.
 struct TuneEntry { int kind, M, Ca, Cb, Ktot, pc, tile, ks; };
 static const TuneEntry g_tune[] = {
@@ -1484,7 +1485,9 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     // slab write + later slab reduction stay small next to the MFMA work
     int target = g_wgrad_target;
     if (!target) {
-        const TuneEntry* te = tune_lookup(2, (int)M, q.rows, q.cols, s->KH, (s->pool ? 1 : 0) + (up_fold ? 2 : 0));
+        const int pcw = (s->pool ? 1 : 0) + (up_fold ? 2 : 0);
+        const TuneEntry* te = g_prec == 1 ? tune_lookup(5, (int)M, q.rows, q.cols, s->KH, pcw) : nullptr;   // bf16x3 rows first
+        if (!te) te = tune_lookup(2, (int)M, q.rows, q.cols, s->KH, pcw);
         target = te ? te->ks : 1024;
     }
     long long S = (target + tiles - 1) / tiles;

@@ -103,6 +103,8 @@ def main():
         dgrad_fn = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
         if x3:
             keys["fwd"] = (3,) + keys["fwd"][1:]
+            if Cin % 4 == 0 and Cout % 4 == 0:
+                keys["wgrad"] = (5,) + keys["wgrad"][1:]
             if Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
                 wt = torch.empty(Cin * KF * KF * Cout, device=dev)
                 lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
@@ -112,7 +114,7 @@ def main():
                 "dgrad": (n_dx, dgrad_fn),
                 "wgrad": (n_dw, lambda: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh, st))}
         for kind, (calls, fn) in runs.items():
-            if not calls or (x3 and (kind == "wgrad" or keys[kind][0] < 3)):   # bf16x3 pass: only its own rows (kinds 3, 4)
+            if not calls or (x3 and keys[kind][0] < 3):   # bf16x3 pass: only its own rows (kinds 3, 4, 5)
                 continue
             Cb = keys[kind][3]
             lib.gim_conv_tune_override(0, 0, 0)
