@@ -91,6 +91,7 @@ struct ConvP {
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
     int kper;     // K-steps per slice
+    int kgrp;     // K order of the fast path: 0 tap-major, else channels per group of the channel-group-major order
     int gx, gy;   // tiles along M / N
     int xcd;      // 1: XCD-aware tile order over a 1-D grid (see the kernel)
 };
@@ -318,11 +319,27 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
 
     // wave-uniform K position, advanced incrementally by load_tiles (fast path)
     int k_c0 = 0, k_ta = 0, k_tb = 0;
+    // K order.  kgrp == 0: tap-major (all channel chunks of a tap, then the next tap).  kgrp = G (a multiple of KB dividing Ca):
+    // channel-group-major - for each group of G channels all taps, G / KB steps per tap.  With G = 32 one sweep over the taps
+    // re-reads the SAME 128-byte lines (32 fp32 channels of a pixel) nine times within ~18 K steps instead of once per tap 4-12
+    // steps apart: the resident workgroups of an XCD then keep their live lines inside its 4 MB L2 (HBM traffic).
+    const int kgrp = p.kgrp;
+    int k_g0 = 0;   // first channel of the current group
     auto seek = [&](int k0) {
-        const int tap = k0 / p.Ca;
-        k_c0 = k0 - tap * p.Ca;
-        k_ta = tap / g.Tw;
-        k_tb = tap - k_ta * g.Tw;
+        if (kgrp) {
+            const int step = k0 / KB, per_tap = kgrp / KB, per_grp = g.Th * g.Tw * per_tap;
+            const int grp = step / per_grp, rem = step - grp * per_grp;
+            const int tap = rem / per_tap;
+            k_g0 = grp * kgrp;
+            k_c0 = k_g0 + (rem - tap * per_tap) * KB;
+            k_ta = tap / g.Tw;
+            k_tb = tap - k_ta * g.Tw;
+        } else {
+            const int tap = k0 / p.Ca;
+            k_c0 = k0 - tap * p.Ca;
+            k_ta = tap / g.Tw;
+            k_tb = tap - k_ta * g.Tw;
+        }
         set_tap(k_ta, k_tb);
     };
 
@@ -362,7 +379,16 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
             if (k0 < 0)
 #endif
             k_c0 += KB;
-            if (k_c0 == p.Ca) {
+            if (kgrp) {
+                if (k_c0 == k_g0 + kgrp) {           // this tap's share of the group is done: next tap, same channels
+                    k_c0 = k_g0;
+                    if (++k_tb == g.Tw) {
+                        k_tb = 0;
+                        if (++k_ta == g.Th) { k_ta = 0; k_g0 += kgrp; k_c0 = k_g0; }   // next channel group
+                    }
+                    set_tap(k_ta, k_tb);
+                }
+            } else if (k_c0 == p.Ca) {
                 k_c0 = 0;
                 if (++k_tb == g.Tw) { k_tb = 0; ++k_ta; }
                 set_tap(k_ta, k_tb);
@@ -1297,6 +1323,10 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
     p.ksplit = (nk + p.kper - 1) / p.kper;
     if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
     p.gx = gx; p.gy = gy;
+    {   // channel-group-major K order where a group is a whole number of K steps and there is more than one tap to sweep
+        static const int korder = getenv("GIM_CONV_KGROUP") ? atoi(getenv("GIM_CONV_KGROUP")) : 0;
+        p.kgrp = (GEN == 0 && korder > 0 && korder % KB == 0 && p.Ca % korder == 0 && p.g.Th * p.g.Tw > 1 && !p.g.ups) ? korder : 0;
+    }
     // XCD-aware tile orders (1: activation tile shared per XCD, 2: weight tile shared per XCD) measured against the plain
     // order on the bench layers: equal within noise on the large layers, 9 % slower on the small-map 512-channel ones
     // (profiles/r01_i_xcd_modes.txt), so the plain order is the default; GIM_CONV_XCD_MODE=1|2 selects the others.
