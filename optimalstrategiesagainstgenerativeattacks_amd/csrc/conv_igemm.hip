@@ -900,12 +900,16 @@ __global__ __launch_bounds__(256, PREC ? GIM_X3_WG_OCC : 1) void conv_wgrad_kern
         }
     }
 
-    float ra[A_PER][VEC], rb[B_PER][VEC];
+    // staging registers; bf16x3: two sets, loads run two K steps ahead of their LDS store (as in conv_igemm_kernel)
+    constexpr int NSET = X3 ? 2 : 1;
+    float raS[NSET][A_PER][VEC], rbS[NSET][B_PER][VEC];
     float bsum[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) bsum[e] = 0.f;
 
-    auto load_tiles = [&](int mb) {
+    auto load_tiles = [&](int mb, auto SETC) {
+        auto& ra = raS[decltype(SETC)::value];
+        auto& rb = rbS[decltype(SETC)::value];
         if constexpr (VEC == 4) {
             const int left = mend - mb;  // > 0
             const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -965,7 +969,9 @@ __global__ __launch_bounds__(256, PREC ? GIM_X3_WG_OCC : 1) void conv_wgrad_kern
     };
     // activations and the bias sums consume the loaded values here, after the MFMA block, never in load_tiles
     const bool act_a = p.a_slope != 1.0f, act_b = p.pre_slope != 1.0f;  // block-uniform
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto SETC) {
+        auto& ra = raS[decltype(SETC)::value];
+        auto& rb = rbS[decltype(SETC)::value];
         if (act_a) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
@@ -1047,16 +1053,18 @@ __global__ __launch_bounds__(256, PREC ? GIM_X3_WG_OCC : 1) void conv_wgrad_kern
     const int tr_b = (8 * h + tr_q) * RSB + (wn0 + 16 * tr_g + 4 * tr_p) * 2;
 
     const int nk = (mend > mbeg) ? (mend - mbeg + BK - 1) / BK : 0;
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, NSET - 1>;
     if (nk > 0) {
-        load_tiles(mbeg);
-        store_tiles(0);
+        load_tiles(mbeg, Set0());
+        store_tiles(0, Set0());
+        if constexpr (X3) {
+            if (nk > 1) load_tiles(mbeg + BK, Set1());
+        }
     }
     __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) load_tiles(mbeg + (ks + 1) * BK);
-        __builtin_amdgcn_sched_barrier(0);  // keep every consumer of the staged registers behind the MFMA block
-        if constexpr (X3) {
+    if constexpr (X3) {
+        auto mma = [&](int buf) {
             const char* Ab = reinterpret_cast<const char*>(&As[buf][0]) + tr_a;
             const char* Bb = reinterpret_cast<const char*>(&Bs[buf][0]) + tr_b;
             bf16x8 a[TM][3], b[TN][3];
@@ -1077,7 +1085,32 @@ __global__ __launch_bounds__(256, PREC ? GIM_X3_WG_OCC : 1) void conv_wgrad_kern
                         if (q < 5) acc2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[jj][TB[q]], acc2[i][jj], 0, 0, 0);
                         else acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[jj][TB[q]], acc[i][jj], 0, 0, 0);
                     }
-        } else
+        };
+        // MAIN: steady-state step with unconditional loads / stores (a load under `if` makes the compiler wait for ALL loads)
+        auto kstep = [&](int ks, auto BUFC, auto MAINC) {
+            constexpr int buf = decltype(BUFC)::value;
+            constexpr bool MAIN = decltype(MAINC)::value;
+            if (MAIN || ks + 2 < nk) load_tiles(mbeg + (ks + 2) * BK, std::integral_constant<int, buf>());
+            __builtin_amdgcn_sched_barrier(0);
+            mma(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1, std::integral_constant<int, buf ^ 1>());
+            __syncthreads();
+        };
+        int ks = 0;
+        for (; ks + 3 < nk; ks += 2) {
+            kstep(ks, std::integral_constant<int, 0>(), std::true_type());
+            kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
+        }
+        for (; ks < nk; ks += 2) {
+            kstep(ks, std::integral_constant<int, 0>(), std::false_type());
+            if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>(), std::false_type());
+        }
+    } else {
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_tiles(mbeg + (ks + 1) * BK, Set0());
+        __builtin_amdgcn_sched_barrier(0);  // keep every consumer of the staged registers behind the MFMA block
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             float a[TM], b[TN];
@@ -1092,8 +1125,9 @@ __global__ __launch_bounds__(256, PREC ? GIM_X3_WG_OCC : 1) void conv_wgrad_kern
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 1 < nk) store_tiles(buf ^ 1);
+        if (ks + 1 < nk) store_tiles(buf ^ 1, Set0());
         __syncthreads();
+    }
     }
 
     if constexpr (X3) {
