@@ -256,9 +256,9 @@ def main():
         dt3, _, _ = timed("bf16x3")
         _glib.load().gim_conv_precision(0)
         x3 = {"value": round(B * world * args.steps / dt3, 3), "unit": "episodes/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
-              "what": "same workload and steps with gim_conv_precision(1): conv / linear forward and dgrad on the bf16 MFMA with every "
+              "what": "same workload and steps with gim_conv_precision(1): conv / linear forward, dgrad and wgrad on the bf16 MFMA with every "
                       "fp32 operand split exactly into three bf16 (6 partial products, fp32 accumulate; error vs fp64 equal to the fp32 "
-                      "MFMA's: tools/micro/bf16x3_gemm.hip, same parity tolerances: tests/test_gpu_bf16x3.py); wgrad stays on the fp32 MFMA"}
+                      "MFMA's or lower on every layer: profiles/r01_k_bf16x3_accuracy_vs_fp64.txt; same parity tolerances: tests/test_gpu_bf16x3.py)"}
     g_loss, d_loss = float(out[0][0]), float(out[1][0])
 
     if rank == 0:
