@@ -343,6 +343,7 @@ class ConvFn(Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
+_DGRAD_T_ALWAYS = os.environ.get("GIM_DGRAD_T") is not None   # A/B switch: transposed-weight dgrad on the fp32 MFMA path too (measured slower: 341 vs 352 episodes/s)
 _WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
 
 
@@ -375,7 +376,7 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
     mask = x if pre_slope != 1.0 else None
     dx = torch.empty_like(x)
     wk = wf if fold else wp
-    if w is not None and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold) and lib.gim_conv_precision(-1) == 1:
+    if w is not None and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold) and (_DGRAD_T_ALWAYS or lib.gim_conv_precision(-1) == 1):
         wt = _transposed(lib, w, wk, Cout, Cin, KH + 1 if fold else KH)
         check(lib.gim_conv2d_dgrad_t(_p(dy), _p(wt), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad_t")
         return dx
