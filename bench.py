@@ -11,6 +11,7 @@ kernel's own roofline from a HIP-event microbenchmark through the C ABI, and the
 port of the reference's path, timed on the host cores on a bounded sample).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -154,8 +155,8 @@ def cpu_baseline(workload, m, n, k, sample_B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="vox64", choices=sorted(UNIT))
     ap.add_argument("--batch", type=int, default=0, help="episodes per GPU (default: 16 for vox64, 32 for om32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -221,6 +222,7 @@ def main():
             out = step()
             torch.cuda.synchronize()
             log("%s: warm-up step %d done" % (label, i))
+        gc.collect()   # start the timed region with an empty young generation (a full collection mid-region stalls the enqueue thread)
         fence()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.time()
