@@ -223,6 +223,8 @@ def main():
             torch.cuda.synchronize()
             log("%s: warm-up step %d done" % (label, i))
         gc.collect()   # start the timed region with an empty young generation (a full collection mid-region stalls the enqueue thread)
+        if os.environ.get("GIM_BENCH_NOGC"):   # diagnostics: is a slow phase the garbage collector?
+            gc.disable()
         fence()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.time()
