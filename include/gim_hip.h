@@ -125,11 +125,12 @@ int gim_conv2d_transpose_weights(const float* w, float* wt, int Cout, int Cin, i
 int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, const float* mask_x, float* dx,
                        const gim_conv_shape* shape, void* stream);
 
-/* Matrix path of the k-contiguous conv / linear contraction (replaces nothing in the reference: F.conv2d has one fp32 path).
+/* Matrix path of the conv / linear contractions (replaces nothing in the reference: F.conv2d has one fp32 path).
  * 0 = v_mfma_f32_32x32x2_f32; 1 = "bf16x3": every fp32 operand is split exactly into three bf16 numbers and six partial
- * products are accumulated in fp32 on the bf16 matrix pipe - fp32-level accuracy at 2.67x fewer matrix-pipe cycles (layers
- * the bf16x3 kernel does not cover keep path 0).  Returns the previous mode; mode < 0 only queries.  GIM_CONV_PREC sets the
- * start value.  Process-wide. */
+ * products are accumulated in fp32 on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) - the fp32 result, measured closer to fp64
+ * than path 0, at 2.67x fewer matrix-pipe cycles.  Applies to gim_conv2d_fwd, gim_conv2d_dgrad_t and gim_conv2d_wgrad / _acc on
+ * their vector paths (channel counts that are multiples of 16 / 4); other launches keep path 0.  Returns the previous mode;
+ * mode < 0 only queries.  GIM_CONV_PREC sets the start value.  Process-wide, not thread-safe against concurrent launches. */
 int gim_conv_precision(int mode);
 
 /* Accumulating weight gradient: ADDS the gradient of one convolution (raw, un-finished: dW, dF or G layout as in
