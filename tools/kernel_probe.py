@@ -27,8 +27,13 @@ def main():
     ns = lib.gim_conv2d_wgrad_slabs(sh)
     slabs = torch.empty(ns * Cout * K * K * Cin, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+    dgrad = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
+    if lib.gim_conv_precision(-1) == 1 and Cout % 16 == 0 and Cin >= 32 and not ups:   # bf16x3 path: dgrad on transposed weights (ops._conv_dgrad)
+        wt = torch.empty(Cin * K * K * Cout, device=dev)
+        lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, K, st)
+        dgrad = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
     fn = {"fwd": lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st),
-          "dgrad": lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st),
+          "dgrad": dgrad,
           "wgrad": lambda: lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st)}[kind]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn()
