@@ -1,0 +1,189 @@
+// Feasibility study for round 2: bf16x3 3x3 convolution with the INPUT PATCH resident in LDS.
+//
+// The engine's bf16x3 kernel (csrc/conv_igemm.hip, PREC 1) re-loads and re-splits every activation element once per filter tap
+// (and N tile): PMC shows VALU = 55 % of its instruction stream, MfmaUtil 38-46 %.  Here a workgroup loads the 4 x 66 pixel patch
+// its 2 x 64 output pixels need ONCE per 32-channel half, splits it once into three bf16 planes in LDS, and then runs all 9 taps
+// x 2 channel chunks (18 K steps of 16) out of that patch: the A operand of tap (ta, tb) is the same LDS image read at a constant
+// offset.  Only the weight tile (64 output channels x 16 k) is streamed and split per K step.
+//   VALU per 32-channel half and thread: 9 float4 of patch (198) + 18 weight float4 (396)  vs  216 MFMAs per wave.
+// Shape family of the dominant layer: NHWC x [N][64][64][64], w [64][3][3][64] (k-contiguous), y [N][64][64][64], pad 1.
+//   hipcc --offload-arch=gfx950 -O3 bf16x3_patch_conv.hip -o bf16x3_patch_conv && ./bf16x3_patch_conv
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int H = 64, W = 64, C = 64, CO = 64;
+constexpr int PW = W + 2;                 // patch width (halo columns)
+constexpr int PIX = 208;                  // bytes per patch pixel: 2 chunks x [hi 32 B][mid][lo] + 16 B pad (conflict-free ds_read_b128)
+constexpr int PATCH = 4 * PW * PIX;       // 54912 B
+constexpr int BROW = 28 * 4;              // bytes per weight row of a K step: [hi][mid][lo] + pad
+constexpr int BTILE = CO * BROW;          // 7168 B
+
+__device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& mid, u32x2& lo) {
+    unsigned xb[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xe = x[e];
+        xb[e] = __builtin_bit_cast(unsigned, xe);
+        const float d1 = xe - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);
+        r1[e] = __builtin_bit_cast(unsigned, d1);
+        const float d2 = d1 - __builtin_bit_cast(float, r1[e] & 0xFFFF0000u);
+        r2[e] = __builtin_bit_cast(unsigned, d2);
+    }
+    hi = u32x2{__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
+    mid = u32x2{__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    lo = u32x2{__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_patch_bf16x3(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) char lds[PATCH + 2 * BTILE];
+    char* patch = lds;
+    char* Bs = lds + PATCH;
+    const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5, wv = t >> 6;
+    const int tile = blockIdx.x;                    // 32 tiles of 2 rows per image
+    const int n = tile >> 5, y0 = (tile & 31) * 2;
+    const float* xin = x + (size_t)n * H * W * C;
+
+    f32x16 acc[2], acc2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[j][e] = 0.f; acc2[j][e] = 0.f; }
+
+    // this wave's 32 output pixels: row yy of the tile, columns x0 .. x0 + 31; patch pixel of tap (0,0) = (yy, x0 + r)
+    const int yy = wv >> 1, x0 = (wv & 1) * 32;
+    const int a_lane = ((yy * PW) + (x0 + r)) * PIX + h * 16;
+    const int b_lane = r * BROW + h * 16;             // weight row r (+32 for the second block)
+
+    // weight tile of one K step: 64 rows x 16 k = 256 float4, one per thread
+    const int brow = t >> 2, bq = t & 3;
+
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                              // the previous half's MFMAs are done with the patch
+        // ---- patch: 4 rows x 66 pixels x 32 channels; 8 float4 per pixel -> 2112 float4 over 256 threads ----
+        for (int idx = t; idx < 4 * PW * 8; idx += 256) {
+            const int q8 = idx & 7, pp = idx >> 3;
+            const int py = pp / PW, px = pp - py * PW;
+            const int iy = y0 - 1 + py, ix = px - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const f32x4*>(xin + ((size_t)iy * W + ix) * C + half * 32 + q8 * 4);
+            u32x2 hi, mid, lo;
+            split4(v, hi, mid, lo);
+            char* d = patch + pp * PIX + (q8 >> 2) * 96 + (q8 & 3) * 8;   // chunk (q8 >> 2), k-quad (q8 & 3)
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + 32) = mid;
+            *reinterpret_cast<u32x2*>(d + 64) = lo;
+        }
+        // ---- 18 K steps: tap-major, 2 chunks per tap; weights register-staged one step ahead ----
+        auto wload = [&](int ks) {
+            const int tap = ks >> 1, ch = ks & 1;
+            return *reinterpret_cast<const f32x4*>(w + ((size_t)brow * 9 + tap) * C + half * 32 + ch * 16 + bq * 4);
+        };
+        auto wstore = [&](int buf, const f32x4& v) {
+            u32x2 hi, mid, lo;
+            split4(v, hi, mid, lo);
+            char* d = Bs + buf * BTILE + brow * BROW + bq * 8;
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + 32) = mid;
+            *reinterpret_cast<u32x2*>(d + 64) = lo;
+        };
+        f32x4 wr = wload(0);
+        wstore(0, wr);
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < 18; ++ks) {
+            const int buf = ks & 1;
+            if (ks + 1 < 18) wr = wload(ks + 1);
+            const int tap = ks >> 1, ch = ks & 1;
+            const int ta = tap / 3, tb = tap - ta * 3;
+            const char* ap = patch + a_lane + (ta * PW + tb) * PIX + ch * 96;
+            const char* bp = Bs + buf * BTILE + b_lane;
+            bf16x8 a[3], b[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ap + pl * 32));
+                b[0][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + pl * 32));
+                b[1][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + 32 * BROW + pl * 32));
+            }
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (q < 5) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[j][TB[q]], acc2[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[j][TB[q]], acc[j], 0, 0, 0);
+                }
+            if (ks + 1 < 18) wstore(buf ^ 1, wr);
+            __syncthreads();
+        }
+    }
+    // accumulator (pixel row e-mapped, column = lane r = output channel within the block)
+    float* yo = y + ((size_t)n * H * W + (size_t)(y0 + yy) * W + x0) * CO;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int px = 8 * (e >> 2) + 4 * h + (e & 3);
+            yo[(size_t)px * CO + 32 * j + r] = acc[j][e] + acc2[j][e];
+        }
+}
+
+int main() {
+    const int N = 320;
+    const size_t nx = (size_t)N * H * W * C, nw = (size_t)CO * 9 * C, ny = (size_t)N * H * W * CO;
+    std::vector<float> hx(nx), hw(nw);
+    unsigned s = 99;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 9) & 0x7FFFFF) / 4194304.0f - 1.0f; };
+    for (auto& v : hx) v = rnd();
+    for (auto& v : hw) v = rnd() * 0.05f;
+    float *x, *w, *y;
+    hipMalloc(&x, nx * 4); hipMalloc(&w, nw * 4); hipMalloc(&y, ny * 4);
+    hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice);
+    hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
+    const dim3 grid(N * 32);
+    hipLaunchKernelGGL(conv3x3_patch_bf16x3, grid, dim3(256), 0, 0, x, w, y);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(conv3x3_patch_bf16x3, grid, dim3(256), 0, 0, x, w, y);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    std::vector<float> hy(ny);
+    hipMemcpy(hy.data(), y, ny * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int q = 0; q < 2000; ++q) {
+        s = s * 1664525u + 1013904223u; const int n = (s >> 8) % N;
+        s = s * 1664525u + 1013904223u; const int oy = (s >> 8) % H;
+        s = s * 1664525u + 1013904223u; const int ox = (s >> 8) % W;
+        s = s * 1664525u + 1013904223u; const int co = (s >> 8) % CO;
+        double ref = 0, mag = 0;
+        for (int ta = 0; ta < 3; ++ta)
+            for (int tb = 0; tb < 3; ++tb) {
+                const int iy = oy + ta - 1, ix = ox + tb - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                for (int c = 0; c < C; ++c) {
+                    const double p = (double)hx[(((size_t)n * H + iy) * W + ix) * C + c] * hw[((size_t)co * 9 + ta * 3 + tb) * C + c];
+                    ref += p; mag += fabs(p);
+                }
+            }
+        worst = fmax(worst, fabs(hy[(((size_t)n * H + oy) * W + ox) * CO + co] - ref) / mag);
+    }
+    const double fl = 2.0 * N * H * W * CO * C * 9;
+    printf("conv 64->64 3x3 @64x64 x%d images, input patch in LDS, bf16x3: %.3f ms  %.1f TFLOP/s  max err / sum|terms| %.2e\n", N, ms, fl / ms / 1e9, worst);
+    printf("(engine on this layer: fp32 MFMA 1.01 ms 96 TFLOP/s; bf16x3 with per-tap loads 0.76 ms 127 TFLOP/s)\n");
+    return 0;
+}
