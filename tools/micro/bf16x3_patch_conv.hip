@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -137,6 +138,99 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_bf16x3(const float* __re
         }
 }
 
+
+// Variant 2: weights PRE-SPLIT once (host here; a per-update kernel in the engine) into the MFMA operand layout
+//   ws[kstep = (half, tap, chunk)][plane][32-channel block][lane (row, k half)][8 bf16]
+// and loaded by every lane STRAIGHT INTO REGISTERS (6 x 16 B per K step, one step ahead): no weight tile in LDS, no split
+// arithmetic and NO BARRIER inside the 18 K steps of a patch - the waves run free between the two patch barriers.
+__global__ __launch_bounds__(256, 2) void conv3x3_patch_bf16x3_wreg(const float* __restrict__ x, const unsigned short* __restrict__ ws,
+                                                                    float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) char patch[PATCH];
+    const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5, wv = t >> 6;
+    const int tile = blockIdx.x;
+    const int n = tile >> 5, y0 = (tile & 31) * 2;
+    const float* xin = x + (size_t)n * H * W * C;
+    f32x16 acc[2], acc2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[j][e] = 0.f; acc2[j][e] = 0.f; }
+    const int yy = wv >> 1, x0 = (wv & 1) * 32;
+    const int a_lane = ((yy * PW) + (x0 + r)) * PIX + h * 16;
+    // ws[kstep][plane][block j][lane (r, h)][16 B]: one load instruction of a wave reads 1 KB of contiguous memory
+    const char* wb = reinterpret_cast<const char*>(ws) + (r * 2 + h) * 16;
+    u32x4 bn[2][3], bc[2][3];
+    auto bload = [&](int kidx, u32x4 (&b)[2][3]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            b[0][pl] = *reinterpret_cast<const u32x4*>(wb + ((kidx * 3 + pl) * 2 + 0) * 1024);
+            b[1][pl] = *reinterpret_cast<const u32x4*>(wb + ((kidx * 3 + pl) * 2 + 1) * 1024);
+        }
+    };
+    bload(0, bn);
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        for (int idx = t; idx < 4 * PW * 8; idx += 256) {
+            const int q8 = idx & 7, pp = idx >> 3;
+            const int py = pp / PW, px = pp - py * PW;
+            const int iy = y0 - 1 + py, ix = px - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const f32x4*>(xin + ((size_t)iy * W + ix) * C + half * 32 + q8 * 4);
+            u32x2 hi, mid, lo;
+            split4(v, hi, mid, lo);
+            char* d = patch + pp * PIX + (q8 >> 2) * 96 + (q8 & 3) * 8;
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + 32) = mid;
+            *reinterpret_cast<u32x2*>(d + 64) = lo;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bc[j][pl] = bn[j][pl];
+            const int knext = half * 18 + ks + 1;
+            if (knext < 36) bload(knext, bn);
+            const int tap = ks >> 1, ch = ks & 1;
+            const int ta = tap / 3, tb = tap - ta * 3;
+            const char* ap = patch + a_lane + (ta * PW + tb) * PIX + ch * 96;
+            bf16x8 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ap + pl * 32));
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, bc[j][TB[q]]);
+                    if (q < 5) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], bv, acc2[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], bv, acc[j], 0, 0, 0);
+                }
+        }
+    }
+    float* yo = y + ((size_t)n * H * W + (size_t)(y0 + yy) * W + x0) * CO;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int px = 8 * (e >> 2) + 4 * h + (e & 3);
+            yo[(size_t)px * CO + 32 * j + r] = acc[j][e] + acc2[j][e];
+        }
+}
+
+static void host_split(float v, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    unsigned b; memcpy(&b, &v, 4);
+    hi = b >> 16;
+    unsigned hb = b & 0xFFFF0000u; float hf; memcpy(&hf, &hb, 4);
+    float r1 = v - hf; unsigned b1; memcpy(&b1, &r1, 4);
+    mid = b1 >> 16;
+    unsigned mb = b1 & 0xFFFF0000u; float mf; memcpy(&mf, &mb, 4);
+    float r2 = r1 - mf; unsigned b2; memcpy(&b2, &r2, 4);
+    lo = b2 >> 16;
+}
+
 int main() {
     const int N = 320;
     const size_t nx = (size_t)N * H * W * C, nw = (size_t)CO * 9 * C, ny = (size_t)N * H * W * CO;
@@ -184,6 +278,41 @@ int main() {
     }
     const double fl = 2.0 * N * H * W * CO * C * 9;
     printf("conv 64->64 3x3 @64x64 x%d images, input patch in LDS, bf16x3: %.3f ms  %.1f TFLOP/s  max err / sum|terms| %.2e\n", N, ms, fl / ms / 1e9, worst);
+    {   // variant 2: pre-split weights straight to registers
+        std::vector<unsigned short> hws((size_t)CO * 36 * 48);
+        for (int co = 0; co < CO; ++co)
+            for (int half = 0; half < 2; ++half)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ch = 0; ch < 2; ++ch)
+                        for (int kk = 0; kk < 16; ++kk) {
+                            const int kidx = half * 18 + tap * 2 + ch;
+                            unsigned short a, b, c;
+                            host_split(hw[((size_t)co * 9 + tap) * C + half * 32 + ch * 16 + kk], a, b, c);
+                            const int j = co >> 5, rr = co & 31, hh = kk >> 3, i8 = kk & 7;
+                            unsigned short pls[3] = {a, b, c};
+                            for (int pl = 0; pl < 3; ++pl)
+                                hws[((((size_t)kidx * 3 + pl) * 2 + j) * 1024 + (rr * 2 + hh) * 16) / 2 + i8] = pls[pl];
+                        }
+        unsigned short* ws;
+        hipMalloc(&ws, hws.size() * 2);
+        hipMemcpy(ws, hws.data(), hws.size() * 2, hipMemcpyHostToDevice);
+        hipMemset(y, 0, ny * 4);
+        hipLaunchKernelGGL(conv3x3_patch_bf16x3_wreg, grid, dim3(256), 0, 0, x, ws, y);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(conv3x3_patch_bf16x3_wreg, grid, dim3(256), 0, 0, x, ws, y);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms2;
+        hipEventElapsedTime(&ms2, e0, e1);
+        ms2 /= reps;
+        std::vector<float> hy2(ny);
+        hipMemcpy(hy2.data(), y, ny * 4, hipMemcpyDeviceToHost);
+        double diff = 0;
+        for (size_t i = 0; i < ny; i += 997) diff = fmax(diff, fabs((double)hy2[i] - hy[i]));
+        printf("  + pre-split weights straight to registers, no barrier in the K loop: %.3f ms  %.1f TFLOP/s  max |diff to variant 1| %.2e\n",
+               ms2, fl / ms2 / 1e9, diff);
+    }
     printf("(engine on this layer: fp32 MFMA 1.01 ms 96 TFLOP/s; bf16x3 with per-tap loads 0.76 ms 127 TFLOP/s)\n");
     return 0;
 }
