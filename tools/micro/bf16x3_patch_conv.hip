@@ -220,6 +220,119 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_bf16x3_wreg(const float*
         }
 }
 
+// Variant 3: variant 2 + the patch load SOFTWARE-PIPELINED under the MFMAs.  Persistent workgroups (one per CU), two patch buffers:
+// while the 18 K steps of stage s (= tile, 32-channel half) run out of one buffer, the 9 float4 per thread of stage s + 1 are in
+// flight from global memory and are split and written into the other buffer one piece every second K step; one barrier per stage.
+__global__ __launch_bounds__(256, 1) void conv3x3_patch_bf16x3_pipe(const float* __restrict__ x, const unsigned short* __restrict__ ws,
+                                                                    float* __restrict__ y, int ntiles) {
+    __shared__ __attribute__((aligned(16))) char patch2[2 * PATCH];
+    const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5, wv = t >> 6;
+    f32x16 acc[2], acc2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[j][e] = 0.f; acc2[j][e] = 0.f; }
+    const int yy = wv >> 1, x0 = (wv & 1) * 32;
+    const int a_lane = ((yy * PW) + (x0 + r)) * PIX + h * 16;
+    const char* wb = reinterpret_cast<const char*>(ws) + (r * 2 + h) * 16;
+    // per-thread constants of the 9 patch pieces
+    int p_lds[9], p_py[9], p_goff[9];
+    bool p_ok[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int idx = t + 256 * i;
+        const int q8 = idx & 7, pp = idx >> 3;
+        const int py = pp / PW, px = pp - py * PW;
+        p_ok[i] = idx < 4 * PW * 8 && (unsigned)(px - 1) < (unsigned)W;
+        p_py[i] = py - 1;
+        p_lds[i] = idx < 4 * PW * 8 ? pp * PIX + (q8 >> 2) * 96 + (q8 & 3) * 8 : -1;
+        p_goff[i] = ((py - 1) * W + (px - 1)) * C + q8 * 4;
+    }
+    f32x4 pv[9];
+    auto issue_loads = [&](int stage) {
+        const int tile = blockIdx.x + (stage >> 1) * gridDim.x, half = stage & 1;
+        const int n = tile >> 5, y0 = (tile & 31) * 2;
+        const float* base = x + ((size_t)n * H * W + (size_t)y0 * W) * C + half * 32;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const bool ok = p_ok[i] && (unsigned)(y0 + p_py[i]) < (unsigned)H;
+            pv[i] = ok ? *reinterpret_cast<const f32x4*>(base + p_goff[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_piece = [&](int i, int bufsel) {
+        if (p_lds[i] < 0) return;
+        u32x2 hi, mid, lo;
+        split4(pv[i], hi, mid, lo);
+        char* d = patch2 + bufsel * PATCH + p_lds[i];
+        *reinterpret_cast<u32x2*>(d) = hi;
+        *reinterpret_cast<u32x2*>(d + 32) = mid;
+        *reinterpret_cast<u32x2*>(d + 64) = lo;
+    };
+    u32x4 bn[2][3], bc[2][3];
+    auto bload = [&](int kidx, u32x4 (&b)[2][3]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            b[0][pl] = *reinterpret_cast<const u32x4*>(wb + ((kidx * 3 + pl) * 2 + 0) * 1024);
+            b[1][pl] = *reinterpret_cast<const u32x4*>(wb + ((kidx * 3 + pl) * 2 + 1) * 1024);
+        }
+    };
+    const int my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int nstages = 2 * my_tiles;
+    if (nstages == 0) return;
+    issue_loads(0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) store_piece(i, 0);
+    bload(0, bn);
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const int cur = s & 1, half = s & 1;
+        const bool more = s + 1 < nstages;
+        if (more) issue_loads(s + 1);
+        const char* pbase = patch2 + cur * PATCH + a_lane;
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bc[j][pl] = bn[j][pl];
+            int knext = half * 18 + ks + 1;
+            if (knext == 36) knext = 0;           // the next stage starts over at half 0
+            bload(knext, bn);
+            const int tap = ks >> 1, ch = ks & 1;
+            const int ta = tap / 3, tb = tap - ta * 3;
+            const char* ap = pbase + (ta * PW + tb) * PIX + ch * 96;
+            bf16x8 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ap + pl * 32));
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, bc[j][TB[q]]);
+                    if (q < 5) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], bv, acc2[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], bv, acc[j], 0, 0, 0);
+                }
+            if (more && (ks & 1) == 0) store_piece(ks >> 1, cur ^ 1);   // one piece of the next patch every second K step
+        }
+        if (half == 1) {
+            const int tile = blockIdx.x + (s >> 1) * gridDim.x;
+            const int n = tile >> 5, y0 = (tile & 31) * 2;
+            float* yo = y + ((size_t)n * H * W + (size_t)(y0 + yy) * W + x0) * CO;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int px = 8 * (e >> 2) + 4 * h + (e & 3);
+                    yo[(size_t)px * CO + 32 * j + r] = acc[j][e] + acc2[j][e];
+                    acc[j][e] = 0.f;
+                    acc2[j][e] = 0.f;
+                }
+        }
+        __syncthreads();
+    }
+}
+
 static void host_split(float v, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
     unsigned b; memcpy(&b, &v, 4);
     hi = b >> 16;
@@ -312,6 +425,23 @@ int main() {
         for (size_t i = 0; i < ny; i += 997) diff = fmax(diff, fabs((double)hy2[i] - hy[i]));
         printf("  + pre-split weights straight to registers, no barrier in the K loop: %.3f ms  %.1f TFLOP/s  max |diff to variant 1| %.2e\n",
                ms2, fl / ms2 / 1e9, diff);
+        for (int wgs = 256; wgs <= 512; wgs += 256) {
+            hipMemset(y, 0, ny * 4);
+            hipLaunchKernelGGL(conv3x3_patch_bf16x3_pipe, dim3(wgs), dim3(256), 0, 0, x, ws, y, N * 32);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(conv3x3_patch_bf16x3_pipe, dim3(wgs), dim3(256), 0, 0, x, ws, y, N * 32);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms3;
+            hipEventElapsedTime(&ms3, e0, e1);
+            ms3 /= reps;
+            hipMemcpy(hy2.data(), y, ny * 4, hipMemcpyDeviceToHost);
+            double diff3 = 0;
+            for (size_t i = 0; i < ny; i += 997) diff3 = fmax(diff3, fabs((double)hy2[i] - hy[i]));
+            printf("  + patch load pipelined under the MFMAs, persistent workgroups (%d): %.3f ms  %.1f TFLOP/s  max |diff to variant 1| %.2e\n",
+                   wgs, ms3, fl / ms3 / 1e9, diff3);
+        }
     }
     printf("(engine on this layer: fp32 MFMA 1.01 ms 96 TFLOP/s; bf16x3 with per-tap loads 0.76 ms 127 TFLOP/s)\n");
     return 0;
