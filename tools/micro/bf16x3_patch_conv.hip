@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_bf16x3_wreg(const float*
 // Variant 3: variant 2 + the patch load SOFTWARE-PIPELINED under the MFMAs.  Persistent workgroups (one per CU), two patch buffers:
 // while the 18 K steps of stage s (= tile, 32-channel half) run out of one buffer, the 9 float4 per thread of stage s + 1 are in
 // flight from global memory and are split and written into the other buffer one piece every second K step; one barrier per stage.
+template <int D>
 __global__ __launch_bounds__(256, 1) void conv3x3_patch_bf16x3_pipe(const float* __restrict__ x, const unsigned short* __restrict__ ws,
                                                                     float* __restrict__ y, int ntiles) {
     __shared__ __attribute__((aligned(16))) char patch2[2 * PATCH];
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_bf16x3_pipe(const float*
         *reinterpret_cast<u32x2*>(d + 32) = mid;
         *reinterpret_cast<u32x2*>(d + 64) = lo;
     };
-    u32x4 bn[2][3], bc[2][3];
+    u32x4 ring[D][2][3];   // weight operands of the next D K steps (D = 1: one step ahead); 18 % D == 0
     auto bload = [&](int kidx, u32x4 (&b)[2][3]) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_bf16x3_pipe(const float*
     issue_loads(0);
 #pragma unroll
     for (int i = 0; i < 9; ++i) store_piece(i, 0);
-    bload(0, bn);
+#pragma unroll
+    for (int d = 0; d < D; ++d) bload(d, ring[d]);
     __syncthreads();
     for (int s = 0; s < nstages; ++s) {
         const int cur = s & 1, half = s & 1;
@@ -291,13 +293,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_bf16x3_pipe(const float*
         const char* pbase = patch2 + cur * PATCH + a_lane;
 #pragma unroll
         for (int ks = 0; ks < 18; ++ks) {
+            u32x4 bc[2][3];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bc[j][pl] = bn[j][pl];
-            int knext = half * 18 + ks + 1;
-            if (knext == 36) knext = 0;           // the next stage starts over at half 0
-            bload(knext, bn);
+                for (int pl = 0; pl < 3; ++pl) bc[j][pl] = ring[ks % D][j][pl];
+            int knext = half * 18 + ks + D;
+            if (knext >= 36) knext -= 36;         // the next stage starts over at half 0
+            bload(knext, ring[ks % D]);
             const int tap = ks >> 1, ch = ks & 1;
             const int ta = tap / 3, tb = tap - ta * 3;
             const char* ap = pbase + (ta * PW + tb) * PIX + ch * 96;
@@ -425,12 +428,19 @@ int main() {
         for (size_t i = 0; i < ny; i += 997) diff = fmax(diff, fabs((double)hy2[i] - hy[i]));
         printf("  + pre-split weights straight to registers, no barrier in the K loop: %.3f ms  %.1f TFLOP/s  max |diff to variant 1| %.2e\n",
                ms2, fl / ms2 / 1e9, diff);
-        for (int wgs = 256; wgs <= 512; wgs += 256) {
+        for (int depth = 1; depth <= 6; depth = depth == 3 ? 6 : depth + 1) {
+            const int wgs = 256;
+            auto launch = [&]() {
+                if (depth == 1) hipLaunchKernelGGL(conv3x3_patch_bf16x3_pipe<1>, dim3(wgs), dim3(256), 0, 0, x, ws, y, N * 32);
+                else if (depth == 2) hipLaunchKernelGGL(conv3x3_patch_bf16x3_pipe<2>, dim3(wgs), dim3(256), 0, 0, x, ws, y, N * 32);
+                else if (depth == 3) hipLaunchKernelGGL(conv3x3_patch_bf16x3_pipe<3>, dim3(wgs), dim3(256), 0, 0, x, ws, y, N * 32);
+                else hipLaunchKernelGGL(conv3x3_patch_bf16x3_pipe<6>, dim3(wgs), dim3(256), 0, 0, x, ws, y, N * 32);
+            };
             hipMemset(y, 0, ny * 4);
-            hipLaunchKernelGGL(conv3x3_patch_bf16x3_pipe, dim3(wgs), dim3(256), 0, 0, x, ws, y, N * 32);
+            launch();
             hipDeviceSynchronize();
             hipEventRecord(e0);
-            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(conv3x3_patch_bf16x3_pipe, dim3(wgs), dim3(256), 0, 0, x, ws, y, N * 32);
+            for (int i = 0; i < reps; ++i) launch();
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms3;
@@ -439,8 +449,8 @@ int main() {
             hipMemcpy(hy2.data(), y, ny * 4, hipMemcpyDeviceToHost);
             double diff3 = 0;
             for (size_t i = 0; i < ny; i += 997) diff3 = fmax(diff3, fabs((double)hy2[i] - hy[i]));
-            printf("  + patch load pipelined under the MFMAs, persistent workgroups (%d): %.3f ms  %.1f TFLOP/s  max |diff to variant 1| %.2e\n",
-                   wgs, ms3, fl / ms3 / 1e9, diff3);
+            printf("  + patch load pipelined under the MFMAs, persistent workgroups, weights %d K step(s) ahead: %.3f ms  %.1f TFLOP/s  max |diff to variant 1| %.2e\n",
+                   depth, ms3, fl / ms3 / 1e9, diff3);
         }
     }
     printf("(engine on this layer: fp32 MFMA 1.01 ms 96 TFLOP/s; bf16x3 with per-tap loads 0.76 ms 127 TFLOP/s)\n");
