@@ -2,18 +2,29 @@
 (generator step + discriminator step, both Adam updates; training/gim_img_training.py:225-239) over synthetic
 inputs already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vox64|om32] [--batch B] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vox64|om32|vox128] [--batch B] [--no-cpu-baseline] ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job episodes/s, the MFMA roofline
-fraction of the step (ALGO FLOP/episode x episodes / time / fp32-MFMA peak), the dominant
-kernel's own roofline from a HIP-event microbenchmark through the C ABI, and the CPU baseline (the oracle, a
-port of the reference's path, timed on the host cores on a bounded sample).
+``--gpus N`` with N > 1 launches itself: when WORLD_SIZE is not set the script starts N child processes (one rank per
+GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), relays rank 0's JSON line
+and exits with the worst return code.  Under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` it
+uses the environment it is given.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job episodes/s; the MFMA roofline of the step -
+the ALGORITHMIC figure of SURVEY.md 8(d) (FLOPs of the unfused reference ops) and, beside it, the EXECUTED figure (the pool /
+sub-pixel folds run 16/36 resp. 100/324 of a 3x3 / 9x9 convolution's taps: that one is the matrix-pipe utilisation); the
+dominant convolution's own roofline from a HIP-event microbenchmark through the C ABI; HBM traffic per step from rocprofv3
+PMC passes of this same command; the CPU baseline (the oracle, a port of the reference's path, timed on the host cores on
+a bounded sample).
 """
 import argparse
+import csv
 import gc
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -57,18 +68,6 @@ def algo_gflop_per_episode(w, m, n, k):
     return 3 * F_im + F_auG + (2 * n * u["E"] + H) + 3 * F_auD
 
 
-def measured_hbm_traffic(workload, B):
-    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE; profiles/*hbm_traffic*.json).  bench.py cannot run the profiler on itself, so this
-    is the last profiled value for the workload, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic_%s_B%d.json" % (workload, B))
-    try:
-        with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_step"])
-    except (OSError, KeyError, ValueError):
-        return None
-
-
 def synthetic_batch(B, m, n, k, C, S, device, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     mk = lambda t: (torch.rand((B, t, C, S, S), generator=g) * 2 - 1).to(device)  # noqa: E731  dataset range is [-1, 1]
@@ -85,44 +84,140 @@ def build_trainer(S, C, n, m, k, device, style_dim=512, reg_param=0.0):
     return G, tr
 
 
-def dominant_kernel_roofline(device):
-    """HIP-event timing of the heaviest convolution of the workload through the C ABI: the encoder's
-    64->64 3x3 conv at 64x64 on the D-step image count (320 images): fwd, dgrad, wgrad."""
-    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+# ----------------------------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: start the ranks ourselves
+# ----------------------------------------------------------------------------------------------------------------------
+def self_launch(n, argv):
+    """N fresh child processes of this script, one per GPU; never os.exec*, and nothing in this parent touches the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)      # rank 0's stdout holds the ONE JSON line (its stderr went straight to ours)
+    sys.stdout.flush()
+    worst = max(rcs, key=abs)
+    if worst:
+        print("[bench] rank return codes: %s" % rcs, file=sys.stderr)
+    return worst
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# HBM traffic of this same command (rocprofv3 PMC, two passes in child processes, before this process touches the GPU)
+# ----------------------------------------------------------------------------------------------------------------------
+def measure_hbm_traffic(args, steps=2, warmup=1, timeout=420):
+    """HBM bytes per step: `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in SEPARATE runs of
+    `python3 bench.py --inner` (the same workload, `steps` timed + `warmup` steps), summed over the kernels launched after the
+    model is built, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2: 128-byte requests tallied at 64 B;
+    WRITE_SIZE exact; both reported in KiB), divided by the steps run.  None if the profiler is not available."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="gim_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "r", "--",
+                   sys.executable, os.path.abspath(__file__), "--inner", "--workload", args.workload, "--batch", str(args.batch),
+                   "--steps", str(steps), "--warmup", str(warmup), "--reg-param", str(args.reg_param)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            t0 = time.time()
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, r.returncode, r.stderr[-300:])
+            kib, seen_conv = 0.0, False
+            rows = list(csv.DictReader(open(files[0])))
+            if rows and "Dispatch_Id" in rows[0]:
+                rows.sort(key=lambda r_: int(r_["Dispatch_Id"]))
+            for row in rows:
+                # model construction (fills / copies of the initialisers) comes before the first engine kernel: not the step's
+                seen_conv = seen_conv or row["Kernel_Name"].startswith(("snb_", "void conv_", "nchw_to_nhwc"))
+                if seen_conv:
+                    kib += float(row["Counter_Value"])
+            tot[ctr] = kib * 1024.0
+            log("traffic pass %s: %.1f s" % (ctr, time.time() - t0))
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return None, "traffic measurement failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    n = steps + warmup
+    fetch, write = 2.0 * tot["FETCH_SIZE"] / n, tot["WRITE_SIZE"] / n
+    return {"hbm_bytes_per_step": fetch + write, "fetch_bytes_per_step": fetch, "write_bytes_per_step": write,
+            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --inner --steps %d "
+                   "--warmup %d; FETCH_SIZE x2 (gfx950), kernels from the first engine launch on, / %d steps" % (steps, warmup, n)}, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# executed work and the dominant convolution
+# ----------------------------------------------------------------------------------------------------------------------
+def summarize_flops(counts, ops):
+    """counts = ops.count_flops() of ONE step -> (executed GFLOP, algorithmic GFLOP of the same launches, per-conv table)."""
+    exe = algo = 0.0
+    per = {}
+    for (kind, cfg), (n, f) in counts.items():
+        exe += n * f
+        if kind == "bgemm":
+            algo += n * f
+            continue
+        algo += n * ops.conv_algorithmic_flops(*cfg)
+        ent = per.setdefault(cfg, {"fwd": 0, "dgrad": 0, "wgrad": 0, "gflop": f / 1e9})
+        ent[kind] += n
+    return exe / 1e9, algo / 1e9, per
+
+
+def dominant_kernel_roofline(per, device):
+    """HIP-event timing, through the C ABI, of the convolution that EXECUTES the most FLOPs per step (launches x executed FLOPs
+    per launch, forward + dgrad + wgrad), with the geometry the step launches it in (fold / pool flags, table row in force)."""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib, ops
     lib = _lib.load()
-    N, H, Cin, Cout, K = 320, 64, 64, 64, 3
-    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, 0, 0.2)
-    x = torch.randn(N, H, H, Cin, device=device)
-    w = torch.randn(Cout, K, K, Cin, device=device) * 0.05
-    y = torch.empty(N, H, H, Cout, device=device)
-    dx = torch.empty_like(x)
-    ns = lib.gim_conv2d_wgrad_slabs(sh)
-    slabs = torch.empty(ns * Cout * K * K * Cin, device=device)
+    cfg = max(per, key=lambda c: per[c]["gflop"] * (per[c]["fwd"] + per[c]["dgrad"] + per[c]["wgrad"]))
+    N, H, W, Cin, Cout, K, ups, pool, fold = cfg
+    prec = ops.conv_precision()
+    sh = _lib.GimConvShape(N, H, W, Cin, Cout, K, ups, 0.2, pool, fold, 0, prec)
+    KF = K + 1 if fold else K
+    x = torch.randn(N, H >> ups, W >> ups, Cin, device=device)
+    w = torch.randn(Cout, KF, KF, Cin, device=device) * 0.05     # folded layout when fold
+    y = torch.randn(N, H >> pool, W >> pool, Cout, device=device)
+    lo = 1 if (ups and fold) else 0
+    dx = torch.empty(N, H >> lo, W >> lo, Cin, device=device)
+    acc = torch.zeros(Cout * KF * KF * Cin, device=device)
     st = torch.cuda.current_stream().cuda_stream
-    flops = 2.0 * N * H * H * Cout * Cin * K * K
+    gf = per[cfg]["gflop"]
+    dgrad = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, x.data_ptr(), dx.data_ptr(), sh, st)   # noqa: E731
+    if prec == 1 and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
+        wt = torch.empty(Cin * KF * KF * Cout, device=device)
+        lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
+        dgrad = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, x.data_ptr(), dx.data_ptr(), sh, st)   # noqa: E731
     out = {}
-    x3 = lib.gim_conv_precision(-1) == 1
-    dgrad = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
-    if x3:   # the engine's dgrad then runs the k-contiguous kernel on cached transposed weights (ops._conv_dgrad)
-        wt = torch.empty(Cin * K * K * Cout, device=device)
-        lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, K, st)
-        dgrad = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
     for name, fn in (("fwd", lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st)),
                      ("dgrad", dgrad),
-                     ("wgrad", lambda: lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st))):
+                     ("wgrad", lambda: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh, st))):
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        reps = 10
+        reps = 20
         for _ in range(reps):
             fn()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        out[name] = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2)}
-    return {"kernel": "conv_igemm 64->64 3x3 @64x64 x320 img (%s)" % ("fwd / dgrad: bf16x3 split on the bf16 MFMA, wgrad: fp32 MFMA" if x3 else "fp32 MFMA"), "gflop_per_launch": round(flops / 1e9, 2), **out,
-            "frac_fwd": round(out["fwd"]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
+        tf = gf / ms
+        out[name] = {"ms": round(ms, 4), "executed_tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+    return {"kernel": "conv N=%d %dx%d %d->%d %dx%d%s%s (%s)" % (N, H, W, Cin, Cout, K, K, ", avg-pool folded (stride-2, %dx%d taps)" % (KF, KF) if pool else "",
+                                                              ", sub-pixel form of the upsampled conv" if (ups and fold) else "",
+                                                              "bf16x3 on the bf16 MFMA" if prec == 1 else "fp32 MFMA"),
+            "launches_per_step": {k_: per[cfg][k_] for k_ in ("fwd", "dgrad", "wgrad")},
+            "executed_gflop_per_launch": round(gf, 2),
+            "algorithmic_gflop_per_launch": round(ops.conv_algorithmic_flops(*cfg) / 1e9, 2), **out}
 
 
 def cpu_baseline(workload, m, n, k, sample_B):
@@ -158,21 +253,52 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="vox64", choices=sorted(UNIT))
-    ap.add_argument("--batch", type=int, default=0, help="episodes per GPU (default: 16 for vox64, 32 for om32)")
+    ap.add_argument("--batch", type=int, default=0, help="episodes per GPU (default: 16 for vox64, 32 for om32, 2 for vox128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-bf16x3", action="store_true", help="skip the informational second measurement on the bf16x3 matrix path")
     ap.add_argument("--reg-param", type=float, default=0.0, help="R1 weight (BASELINE's metric is quoted at 0; 10 = the paper's VoxCeleb2 setting)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous only: argument parsing, process group, one all-reduce, JSON line")
+    ap.add_argument("--inner", action="store_true", help="(used by the traffic passes) run the steps and print nothing else")
     args = ap.parse_args()
+    u = UNIT[args.workload]
+    m, n, k = u.get("mnk", (1, 5, 10))
+    args.batch = args.batch or u.get("batch", 16 if args.workload == "vox64" else 32)
+    B = args.batch
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    # rehearsal knobs for a 1-GPU box: GIM_BENCH_BACKEND=gloo GIM_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    # rehearsal knobs for a 1-GPU box / the CPU tests: GIM_BENCH_BACKEND=gloo; GIM_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0
     backend = os.environ.get("GIM_BENCH_BACKEND", "nccl")
+
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group(backend if backend != "nccl" or torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+            t = torch.ones(1) * (rank + 1)
+            dist.all_reduce(t)
+            assert float(t) == world * (world + 1) / 2
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                              "backend": dist.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
+                              "config": {"workload": args.workload, "global_batch": B * world}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # HBM traffic first: the profiled runs are child processes and this process has not touched the GPU yet
+    traffic, traffic_note = None, "not measured"
+    if world == 1 and not (args.no_traffic or args.inner or args.graph or os.environ.get("GIM_BENCH_NO_TRAFFIC")):
+        traffic, traffic_note = measure_hbm_traffic(args)
+        log("HBM traffic: %s" % (traffic["hbm_bytes_per_step"] if traffic else traffic_note))
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     if os.environ.get("GIM_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -183,9 +309,6 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    u = UNIT[args.workload]
-    m, n, k = u.get("mnk", (1, 5, 10))
-    B = args.batch or u.get("batch", 16 if args.workload == "vox64" else 32)
     G, tr = build_trainer(u["S"], u["C"], n, m, k, device, reg_param=args.reg_param)
     trainer = G.EpisodeParallel(tr)
     trainer.broadcast_parameters()
@@ -213,81 +336,104 @@ def main():
 
     import warnings
     warnings.filterwarnings("ignore")
-    from optimalstrategiesagainstgenerativeattacks_amd import _lib as _glib
     from optimalstrategiesagainstgenerativeattacks_amd import ops as _ops
 
     def timed(label):
-        """W warm-up steps, then EXACTLY K steps between barrier + synchronize; (seconds [max over ranks], device ms, last out)."""
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize;
+        (seconds [max over ranks], device ms of the region, per-step device ms on the caller's stream, last out)."""
         for i in range(args.warmup):
             out = step()
             torch.cuda.synchronize()
             log("%s: warm-up step %d done" % (label, i))
         gc.collect()   # start the timed region with an empty young generation (a full collection mid-region stalls the enqueue thread)
-        if os.environ.get("GIM_BENCH_NOGC"):   # diagnostics: is a slow phase the garbage collector?
-            gc.disable()
         fence()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream()
         t0 = time.time()
         ev0.record()
         marks = []
         for _ in range(args.steps):
             out = step()
-            if os.environ.get("GIM_BENCH_STEP_EVENTS"):   # diagnostics: where the caller's stream stands after every step
-                marks.append(torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)))
+            marks.append(cur.record_event(torch.cuda.Event(enable_timing=True)))   # no synchronisation: one event record per step
         _ops.join_lanes()   # the last discriminator step runs on its own stream: ev1 must come after it
         ev1.record()
         fence()
-        if marks:
-            ts = [ev0.elapsed_time(m) for m in marks]
-            log("%s: per-step ms on the caller's stream: %s" % (label, " ".join("%.1f" % (b - a) for a, b in zip([0.0] + ts[:-1], ts))))
         dt = time.time() - t0
         dev_ms = ev0.elapsed_time(ev1)
+        ts = [ev0.elapsed_time(mk) for mk in marks]
+        per_step = [b - a for a, b in zip([0.0] + ts[:-1], ts)]
         log("%s: timed region done: %.3f s for %d steps" % (label, dt, args.steps))
         if world > 1:
             tmax = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        return dt, dev_ms, out
+        return dt, dev_ms, per_step, out
 
-    log("models built; warm-up")
-    matrix_path = "bf16x3" if _glib.load().gim_conv_precision(-1) == 1 else "fp32 MFMA"
-    dt, dev_ms, out = timed(matrix_path)
-    # Informational second measurement, never `value`: the same K steps with the forward / dgrad contractions on the bf16
-    # matrix pipe by exact 3-way operand splitting (gim_conv_precision(1): fp32-level error, tests/test_gpu_bf16x3.py)
+    if args.inner:   # a traffic pass: the steps only
+        for _ in range(args.warmup + args.steps):
+            step()
+        _ops.join_lanes()
+        fence()
+        return
+
+    log("models built; counting the executed work of one step")
+    with _ops.count_flops() as counts:   # one extra (un-timed) step with the per-launch accounting switched on
+        step()
+        _ops.join_lanes()
+        torch.cuda.synchronize()
+    exe_gf, algo_launch_gf, per_conv = summarize_flops(counts, _ops)
+
+    matrix_path = "bf16x3" if _ops.conv_precision() == 1 else "fp32 MFMA"
+    dt, dev_ms, per_step, out = timed(matrix_path)
+    # Informational second measurement, never `value`: the same K steps with the contractions on the bf16 matrix pipe by exact
+    # 3-way operand splitting (ops.set_conv_precision(1): fp32-level error, tests/test_gpu_bf16x3.py)
     x3 = None
     if matrix_path == "fp32 MFMA" and not args.no_bf16x3 and graphed is None and world == 1:
-        _glib.load().gim_conv_precision(1)
-        dt3, _, _ = timed("bf16x3")
-        _glib.load().gim_conv_precision(0)
+        _ops.set_conv_precision(1)
+        dt3, _, _, _ = timed("bf16x3")
+        _ops.set_conv_precision(0)
         x3 = {"value": round(B * world * args.steps / dt3, 3), "unit": "episodes/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
-              "what": "same workload and steps with gim_conv_precision(1): conv / linear forward, dgrad and wgrad on the bf16 MFMA with every "
+              "what": "same workload and steps with gim_conv_shape.prec = 1: conv / linear forward, dgrad and wgrad on the bf16 MFMA with every "
                       "fp32 operand split exactly into three bf16 (6 partial products, fp32 accumulate; error vs fp64 equal to the fp32 "
                       "MFMA's or lower on every layer: profiles/r01_k_bf16x3_accuracy_vs_fp64.txt; same parity tolerances: tests/test_gpu_bf16x3.py)"}
     g_loss, d_loss = float(out[0][0]), float(out[1][0])
 
     if rank == 0:
         eps = B * world * args.steps / dt
+        med = sorted(per_step)[len(per_step) // 2] if len(per_step) % 2 else 0.5 * sum(sorted(per_step)[len(per_step) // 2 - 1:len(per_step) // 2 + 1])
         algo = algo_gflop_per_episode(args.workload, m, n, k)
-        achieved = eps * algo / 1e3 / world  # TFLOP/s per GPU
+        achieved = eps * algo / 1e3 / world            # ALGORITHMIC TFLOP/s per GPU (SURVEY.md 8(d) convention)
+        executed = exe_gf / 1e3 / (dt / args.steps)     # EXECUTED TFLOP/s per GPU (this rank's launches)
         line = {
             "metric": "GIM episodes/sec (%dx%dx%d, m=%d n=%d k=%d)" % (u["S"], u["S"], u["C"], m, n, k),
             "value": round(eps, 3), "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_median": round(med, 3), "value_at_median_step": round(B * world / med * 1e3, 3),
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "config": {"workload": "%s: %dx%dx%d synthetic episodes, m=%d n=%d k=%d, %d episodes/GPU, style_dim=512, "
                                    "G step + D step + 2 Adam updates per step, reg_param=%g" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B, args.reg_param),
                        "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world,
+                       "backend": dist.get_backend() if dist.is_initialized() else None,
                        "launch": "hipGraph replay" if args.graph else "eager", "matrix_path": matrix_path},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": measured_hbm_traffic(args.workload, B) if world == 1 else None, "traffic_unit": "HBM bytes/step (rocprofv3 PMC, profiles/)",
-                         "algo_gflop_per_episode": round(algo, 1), "device_ms_per_step": round(dev_ms / args.steps, 3)},
+                         "what": "achieved / frac: ALGORITHMIC FLOPs (SURVEY.md 8(d): the unfused reference ops at full resolution) per second; the "
+                                 "matrix-pipe utilisation is executed_frac: FLOPs the kernels execute (pool / sub-pixel folds: (K+1)^2 taps at a "
+                                 "quarter of the pixels), counted per launch over one step",
+                         "algo_gflop_per_episode": round(algo, 1), "algo_gflop_per_step": round(algo * B, 1),
+                         "executed_gflop_per_step": round(exe_gf, 1), "executed_tflops": round(executed, 3),
+                         "executed_frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "launched_ops_at_full_resolution_gflop_per_step": round(algo_launch_gf, 1),
+                         "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
+                         "traffic_unit": "HBM bytes/step", "traffic_detail": traffic if traffic else traffic_note,
+                         "device_ms_per_step": round(dev_ms / args.steps, 3)},
             "final_losses": {"g": round(g_loss, 5), "d": round(d_loss, 5)},
         }
         if x3 is not None:
             line["bf16x3_path"] = x3
         if not args.no_kernel_bench:
-            line["dominant_kernel"] = dominant_kernel_roofline(device)
+            line["dominant_kernel"] = dominant_kernel_roofline(per_conv, device)
             log("kernel microbenchmark done")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, m, n, k, sample_B=2)

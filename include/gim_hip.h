@@ -10,7 +10,11 @@
  *  - activations are NHWC ([N][H][W][C], C fastest); conv weights are [Cout][KH][KW][Cin]
  *    (= the reference's [Cout,Cin,KH,KW] parameter stored channels-last); linear weights are [out][in];
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing, owns
- *    nothing, keeps no global mutable state and is safe to capture into a hipGraph;
+ *    nothing and is safe to capture into a hipGraph; the library keeps NO mutable process-wide state and reads NO
+ *    environment variables: everything a launch depends on is in its arguments (matrix path and launch overrides are
+ *    fields of gim_conv_shape) or in the read-only per-shape launch table compiled into the library
+ *    (csrc/conv_tune_table.inc).  Concurrent calls from several threads / streams are independent (gim_last_error()
+ *    is thread-local);
  *  - spatial sizes H, W are powers of two (the reference's Encoder/EnvDecoder require img_size = 2^k,
  *    models/gim_img_models.py:30,72);
  *  - return 0 on success, negative GIM_E_* otherwise; gim_last_error() gives a message.
@@ -41,11 +45,24 @@ int gim_version(void);
  *   wfold   = 1: `w` points to the folded weights F of gim_conv2d_fold_weights ([Cout][KH+1][KH+1][Cin]).  With
  *                ups = 1 the convolution of the upsampled image is computed in its sub-pixel form (4 output-parity
  *                classes, ((KH+1)/2)^2 taps each on the LOW-resolution x): same FLOP ratios as above.
- *   res_ups = 1: (forward) the residual is stored at half resolution and nearest-upsampled on the fly. */
+ *   res_ups = 1: (forward) the residual is stored at half resolution and nearest-upsampled on the fly.
+ *   prec    : matrix path of THIS call (replaces nothing in the reference: F.conv2d has one fp32 path).
+ *             0 = v_mfma_f32_32x32x2_f32; 1 = "bf16x3": every fp32 operand is split exactly into three bf16 numbers and six
+ *             partial products are accumulated in fp32 on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) - the fp32 result,
+ *             measured closer to fp64 than path 0, at 2.67x fewer matrix-pipe cycles.  Honoured by gim_conv2d_fwd,
+ *             gim_conv2d_dgrad_t and gim_conv2d_wgrad / _acc on their vector paths (channel counts that are multiples of
+ *             16 / 4); other launches run path 0.
+ *   tune_tile / tune_ksplit / tune_wgrad : launch overrides for tools/conv_autotune.py and the tuned-row parity tests; 0
+ *             (the product's value) = the table row of this shape, else the heuristic.  tune_tile: 128 = 128x128, 641 =
+ *             64x128, 1264 = 128x64, 64 = 64x64 output tile, < 0 = ignore the table; tune_ksplit: split-K factor of
+ *             fwd / dgrad; tune_wgrad: workgroup target of the wgrad pixel slicing.  Results never depend on them beyond
+ *             the summation order. */
 typedef struct {
     int32_t N, H, W, Cin, Cout, KH, ups;
     float pre_slope;
     int32_t pool, wfold, res_ups;
+    int32_t prec;
+    int32_t tune_tile, tune_ksplit, tune_wgrad;
 } gim_conv_shape;
 
 /* F[co][a][b][ci] = sum_{dh,dw in {0,1}} w[co][a-dh][b-dw][ci], a, b in [0, KH]  (out-of-range taps are zero). */
@@ -72,7 +89,9 @@ int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const 
  * dy^T * im2col(x~): layout [Cout][KH][KW][Cin] (plain), [Cout][KH+1][KH+1][Cin] (pool: gradient of F) or
  * [Cin][KH+1][KH+1][Cout] (ups + wfold: transposed gradient of F; no bias_slabs in this form);  bias_slabs[i] ([Cout] each, may be NULL) the matching partial
  * sums of dy over pixels (the bias gradient, produced from the dy tiles the kernel streams anyway).
- * n_slabs from gim_conv2d_wgrad_slabs(). */
+ * n_slabs = gim_conv2d_wgrad_slabs(shape): deterministic (each pixel slice writes its own slab, gim_wgrad_finish adds them in
+ * a fixed order); n_slabs = 1: the slices add into ONE slab with float atomics (cleared by the call; summation order varies
+ * from run to run in the last bits). */
 int gim_conv2d_wgrad_slabs(const gim_conv_shape* s);
 int gim_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs, const gim_conv_shape* s,
                      void* stream);
@@ -112,11 +131,6 @@ typedef struct {
 int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, const int32_t* tab_cols, int n_col_blocks,
                                const int32_t* tab_rows, int n_row_blocks, float* out_base, int training, void* stream);
 
-/* Autotuner hook (tools/conv_autotune.py): force the tile configuration (128 = 128x128, 641 = 64x128, 1264 = 128x64,
- * 64 = 64x64), the split-K factor and the wgrad slice target of all following conv launches; zeros restore the table /
- * heuristics.  Process-wide, not thread-safe: for tuning runs only. */
-int gim_conv_tune_override(int tile_cfg, int ksplit, int wgrad_target);
-
 /* dgrad on TRANSPOSED weights: the input gradient of gim_conv2d_fwd as gim_conv2d_dgrad computes it (same shape struct, same
  * fused mask / 1/sigma / folds), but reading WT[Cin][KF][KF][Cout] (gim_conv2d_transpose_weights of the plain or folded
  * weights), whose rows are k-contiguous for this contraction: dgrad then runs the forward kernel's operand path, bf16x3
@@ -125,13 +139,12 @@ int gim_conv2d_transpose_weights(const float* w, float* wt, int Cout, int Cin, i
 int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, const float* mask_x, float* dx,
                        const gim_conv_shape* shape, void* stream);
 
-/* Matrix path of the conv / linear contractions (replaces nothing in the reference: F.conv2d has one fp32 path).
- * 0 = v_mfma_f32_32x32x2_f32; 1 = "bf16x3": every fp32 operand is split exactly into three bf16 numbers and six partial
- * products are accumulated in fp32 on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) - the fp32 result, measured closer to fp64
- * than path 0, at 2.67x fewer matrix-pipe cycles.  Applies to gim_conv2d_fwd, gim_conv2d_dgrad_t and gim_conv2d_wgrad / _acc on
- * their vector paths (channel counts that are multiples of 16 / 4); other launches keep path 0.  Returns the previous mode;
- * mode < 0 only queries.  GIM_CONV_PREC sets the start value.  Process-wide, not thread-safe against concurrent launches. */
-int gim_conv_precision(int mode);
+/* Introspection (tests, tools/conv_autotune.py): the launch an entry point would make for `shape`, nothing is launched.
+ *   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
+ *   out[8] = {1 if a row of the compiled-in per-shape launch table matched, tile rows, tile columns, split-K factor
+ *             (wgrad: pixel slices), grid x, y, z, matrix path the kernel runs (0 fp32 MFMA, 1 bf16x3)}.
+ * A batch beyond the 32-bit buffer-offset range (the entry points then halve it) reports the plan of its last half. */
+int gim_conv_launch_plan(const gim_conv_shape* shape, int kind, int32_t* out);
 
 /* Accumulating weight gradient: ADDS the gradient of one convolution (raw, un-finished: dW, dF or G layout as in
  * gim_conv2d_wgrad) into `acc` / `bias_acc` with float atomics and clears nothing - the caller hands in zeroed (or

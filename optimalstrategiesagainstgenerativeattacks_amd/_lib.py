@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("GIM_LIB_PATH") or os.path.join(_HERE, "csrc", "libgim
 class GimConvShape(ctypes.Structure):
     _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("KH", c_int32), ("ups", c_int32), ("pre_slope", c_float),
-                ("pool", c_int32), ("wfold", c_int32), ("res_ups", c_int32)]
+                ("pool", c_int32), ("wfold", c_int32), ("res_ups", c_int32),
+                ("prec", c_int32), ("tune_tile", c_int32), ("tune_ksplit", c_int32), ("tune_wgrad", c_int32)]
 
 
 P = c_void_p
@@ -61,8 +62,7 @@ SIGNATURES = {
     "gim_wgrad_finish_batched": [P, c_int, P, c_int, P, c_int, P],
     "gim_colsum_acc": [P, P, P, c_int64, c_int, P],
     "gim_colsum2": [P, P, P, P, c_int, c_int, c_int, P],
-    "gim_conv_tune_override": [c_int, c_int, c_int],
-    "gim_conv_precision": [c_int],
+    "gim_conv_launch_plan": [SP, c_int, P],
     "gim_conv2d_transpose_weights": [P, P, c_int, c_int, c_int, P],
     "gim_conv2d_dgrad_t": [P, P, P, P, P, SP, P],
     "gim_episode_gather": [P, P, P, P, c_int, c_int, c_int, c_int, P],

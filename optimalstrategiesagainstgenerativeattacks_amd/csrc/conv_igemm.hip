@@ -83,7 +83,9 @@ struct ConvP {
     int Ktot;
     const float* zero;  // 16 bytes of zeros (out-of-range lanes load from here)
     unsigned x_bytes;   // size of the gathered tensor (buffer-resource range of the fast path)
-    int tune_ks;        // host only: split-K factor from the tuning table (0 = heuristic)
+    int tune_ks;        // host only: split-K factor (caller's, else the tuning table's; 0 = heuristic)
+    int tune_tile;      // host only: tile configuration forced by the caller (0 = table / heuristic, < 0 = heuristic only)
+    int y_zeroed;       // host only: the caller guarantees y holds zeros (split-K launches then skip their memset)
     int prec;           // host only: 1 = bf16x3 matrix path where the kernel has one
     int tune_kind;      // host only: row kind of the launch-tuning table (0 fwd, 1 dgrad k-major, 3 fwd bf16x3, 4 dgrad on transposed weights)
     float pos_inf;      // +infinity as a run-time value
@@ -91,9 +93,6 @@ struct ConvP {
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
     int kper;     // K-steps per slice
-    int kgrp;     // K order of the fast path: 0 tap-major, else channels per group of the channel-group-major order
-    int gx, gy;   // tiles along M / N
-    int xcd;      // 1: XCD-aware tile order over a 1-D grid (see the kernel)
 };
 
 // GENF bit 0: generic K (channel count of the gathered tensor not a multiple of 16, or unaligned base)
@@ -145,20 +144,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define X3_LDR 28
 
 // 4 consecutive-k floats -> 3 planes x 4 bf16, written as three ds_write_b64 (dst = row base + 2 * k-quad, in dwords)
-__device__ __forceinline__ void x3_split_store(unsigned* dst, const f32x4& x, bool is_b = false) {
-#if defined(GIM_DBG_X3_NOSPLIT) || defined(GIM_DBG_X3_NOSPLITB)   // timing experiments: same LDS writes, no split arithmetic
-#ifdef GIM_DBG_X3_NOSPLITB
-    if (is_b)
-#endif
-    {
-        const u32x2 a = {__builtin_bit_cast(unsigned, (float)x[0]), __builtin_bit_cast(unsigned, (float)x[1])};
-        const u32x2 b = {__builtin_bit_cast(unsigned, (float)x[2]), __builtin_bit_cast(unsigned, (float)x[3])};
-        *reinterpret_cast<u32x2*>(dst) = a;
-        *reinterpret_cast<u32x2*>(dst + 8) = b;
-        *reinterpret_cast<u32x2*>(dst + 16) = a;
-        return;
-    }
-#endif
+__device__ __forceinline__ void x3_split_store(unsigned* dst, const f32x4& x) {
     unsigned r1[4], r2[4], xb[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -213,29 +199,10 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         kslice = blockIdx.z >> 2;
     }
     const int t = threadIdx.x;
-    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  XCD-aware order: XCD x
-    // walks a contiguous chunk of M tiles, and for each M tile all its N tiles back to back, so the activation
-    // tile (shared by the N tiles) and the halo rows (shared by neighbouring M tiles) are re-read from that XCD's
-    // own L2 instead of HBM.  Placement only affects speed, never results.
-    int mt = blockIdx.x, nt = blockIdx.y;
-    if (p.xcd == 1) {
-        const int chunk = (p.gx + 7) >> 3;
-        const int x = blockIdx.x & 7, sidx = blockIdx.x >> 3;
-        mt = x * chunk + sidx / p.gy;
-        nt = sidx - (sidx / p.gy) * p.gy;
-        if (mt >= p.gx || sidx >= chunk * p.gy) return;  // padding blocks of the rounded-up grid
-    } else if (p.xcd == 2) {
-        // weight-heavy layers (small maps, 512 channels): the WEIGHT tile is the big operand.  N-major order: XCD x walks a
-        // contiguous range of (N tile, M tile) pairs, so each XCD's L2 holds one or two weight tiles instead of all of them
-        const int total = p.gx * p.gy, chunk = (total + 7) >> 3;
-        const int x = blockIdx.x & 7, sidx = blockIdx.x >> 3;
-        const int L = x * chunk + sidx;
-        if (sidx >= chunk || L >= total) return;
-        nt = L / p.gx;
-        mt = L - nt * p.gx;
-    }
-    const int m0 = mt * BM;
-    const int n0 = nt * BN;
+    // Plain tile order.  (XCD-aware orders - one XCD per contiguous chunk of M tiles, or of weight tiles - were measured in
+    // round 1: they cut the L2 misses of the dominant layer by 13 % and were not faster, profiles/r01_i_xcd_modes.txt.)
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
     const int arow = t / QPR, aq = (t % QPR) * 4;
     const int He = g.Hin << g.ups, We = g.Win << g.ups;  // extent of the (virtually upsampled) gathered image
     const int KF2 = g.KF * g.KF;
@@ -319,27 +286,13 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
 
     // wave-uniform K position, advanced incrementally by load_tiles (fast path)
     int k_c0 = 0, k_ta = 0, k_tb = 0;
-    // K order.  kgrp == 0: tap-major (all channel chunks of a tap, then the next tap).  kgrp = G (a multiple of KB dividing Ca):
-    // channel-group-major - for each group of G channels all taps, G / KB steps per tap.  With G = 32 one sweep over the taps
-    // re-reads the SAME 128-byte lines (32 fp32 channels of a pixel) nine times within ~18 K steps instead of once per tap 4-12
-    // steps apart: the resident workgroups of an XCD then keep their live lines inside its 4 MB L2 (HBM traffic).
-    const int kgrp = p.kgrp;
-    int k_g0 = 0;   // first channel of the current group
+    // K order: tap-major (all channel chunks of a tap, then the next tap).  (A channel-group-major order halved the L2 misses of
+    // the dominant layer in round 1 and was not faster: profiles/r01_k_conv_k_order.txt.)
     auto seek = [&](int k0) {
-        if (kgrp) {
-            const int step = k0 / KB, per_tap = kgrp / KB, per_grp = g.Th * g.Tw * per_tap;
-            const int grp = step / per_grp, rem = step - grp * per_grp;
-            const int tap = rem / per_tap;
-            k_g0 = grp * kgrp;
-            k_c0 = k_g0 + (rem - tap * per_tap) * KB;
-            k_ta = tap / g.Tw;
-            k_tb = tap - k_ta * g.Tw;
-        } else {
-            const int tap = k0 / p.Ca;
-            k_c0 = k0 - tap * p.Ca;
-            k_ta = tap / g.Tw;
-            k_tb = tap - k_ta * g.Tw;
-        }
+        const int tap = k0 / p.Ca;
+        k_c0 = k0 - tap * p.Ca;
+        k_ta = tap / g.Tw;
+        k_tb = tap - k_ta * g.Tw;
         set_tap(k_ta, k_tb);
     };
 
@@ -375,20 +328,8 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
                 }
             }
             // advance the uniform K position by one step (Ca % KB == 0 on this path)
-#ifdef GIM_DBG_SAMEADDR
-            if (k0 < 0)
-#endif
             k_c0 += KB;
-            if (kgrp) {
-                if (k_c0 == k_g0 + kgrp) {           // this tap's share of the group is done: next tap, same channels
-                    k_c0 = k_g0;
-                    if (++k_tb == g.Tw) {
-                        k_tb = 0;
-                        if (++k_ta == g.Th) { k_ta = 0; k_g0 += kgrp; k_c0 = k_g0; }   // next channel group
-                    }
-                    set_tap(k_ta, k_tb);
-                }
-            } else if (k_c0 == p.Ca) {
+            if (k_c0 == p.Ca) {
                 k_c0 = 0;
                 if (++k_tb == g.Tw) { k_tb = 0; ++k_ta; }
                 set_tap(k_ta, k_tb);
@@ -485,7 +426,7 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
             for (int i = 0; i < B_ROWS; ++i) {
                 const int row = arow + RP * i;
                 if constexpr (X3) {
-                    if (BN % RP == 0 || row < BN) x3_split_store(reinterpret_cast<unsigned*>(Bs) + buf * B_SZ + row * LDA + (aq >> 1), rb0[i], true);
+                    if (BN % RP == 0 || row < BN) x3_split_store(reinterpret_cast<unsigned*>(Bs) + buf * B_SZ + row * LDA + (aq >> 1), rb0[i]);
                 } else {
                     if (BN % RP == 0 || row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
                 }
@@ -551,16 +492,12 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         // number of loads in flight path dependent, and the compiler then waits with the smaller count: vmcnt(2..0) instead
         // of vmcnt(5..3) in front of the bf16x3 path's store, which drains the loads issued two steps ahead as well.)
         constexpr bool MAIN = decltype(MAINC)::value;
-#ifndef GIM_DBG_NOLOAD   // timing experiments only (tools/micro/build_dbg.sh): results are wrong with any GIM_DBG_* flag
         if constexpr (X3) {
             if (MAIN || ks + 2 < nk) load_tiles((ks + 2) * KB, std::integral_constant<int, buf>());   // this set's step was stored before the last barrier
         } else {
             if (ks + 1 < nk) load_tiles((ks + 1) * KB, Set0());
         }
-#endif
-#ifndef GIM_NO_IGEMM_FENCE
         __builtin_amdgcn_sched_barrier(0);  // nothing that touches the staged registers may move into the MFMA block
-#endif
         const float* Ab = As + buf * A_SZ;
         const float* Bb = Bs + buf * B_SZ;
         if constexpr (N16) {
@@ -611,12 +548,6 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
 #pragma unroll
         for (int kk = 0; kk < KB / 8; ++kk) {
             f32x4 a[TM], b[TN];
-#ifdef GIM_DBG_NOLDS
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = raS[0][i % A_ROWS] + (float)kk;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = raS[0][(j + 1) % A_ROWS] - (float)kk;
-#else
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + 32 * i + r) * LDK + 8 * kk + 4 * h]);
 #pragma unroll
@@ -628,7 +559,6 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
                     for (int e = 0; e < 4; ++e) b[j][e] = Bb[(8 * kk + 4 * h + e) * BN + wn0 + 32 * j + r];
                 }
             }
-#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -637,15 +567,9 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
-#ifndef GIM_NO_IGEMM_FENCE
         __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef GIM_DBG_NOSTORE
         if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1, std::integral_constant<int, X3 ? (buf ^ 1) : 0>());
-#endif
-#ifndef GIM_DBG_NOBARRIER
         __syncthreads();
-#endif
     };
     int ks = ks0;
     if constexpr (X3) {
@@ -831,13 +755,7 @@ __device__ __forceinline__ void x3_split_store_planes(char* dst, int plane_bytes
 }
 
 template <int BM, int BN, int TM, int TN, int VEC, bool FASTB, int PREC = 0>
-#ifndef GIM_X3_WG_OCC
-#define GIM_X3_WG_OCC 2
-#endif
-#ifndef GIM_X3_WG_LDSPAD
-#define GIM_X3_WG_LDSPAD 0     // experiments: extra LDS bytes per workgroup (caps how many share a CU)
-#endif
-__global__ __launch_bounds__(256, PREC ? GIM_X3_WG_OCC : 1) void conv_wgrad_kernel(const WgP p) {
+__global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP p) {
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -852,7 +770,7 @@ __global__ __launch_bounds__(256, PREC ? GIM_X3_WG_OCC : 1) void conv_wgrad_kern
     constexpr int A_FLOATS = X3 ? 3 * PLA / 4 : BK * BM, B_FLOATS = X3 ? 3 * PLB / 4 : BK * BN;
     static_assert(!X3 || 2 * A_FLOATS >= 256 * VEC, "bias reduction scratch");
     __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS + (X3 ? GIM_X3_WG_LDSPAD / 8 : 0)];
+    __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
 
     const Geo& g = p.g;
     const int t = threadIdx.x;
@@ -1285,24 +1203,15 @@ static Geo geo_pc(const gim_conv_shape* s, int kind) {
     return g;
 }
 
-// K step 32 measured SLOWER on MI355X (104 vs 111 episodes/s: 73 KB of LDS per workgroup leaves 2 waves per
-// SIMD instead of 3); kept as an opt-in for A/B runs.
-static const bool g_force_kb16 = getenv("GIM_CONV_KB32") == nullptr;
-// (A prefetch distance of 2 K steps, with a second register stage, was measured and brought nothing - 175 vs 177
-// episodes/s: the mid-size layers were bound by address arithmetic, not by load latency.)
-
-// Layers whose output tiles do not fill the chip (8x8 and smaller maps, the decoder head, linears) are sliced
-// along K over grid.z.  Measured sweep on MI355X (profiles/r01_ksplit_sweep.txt): best when the launch has about
-// two workgroups per CU (~512); beyond 6 slices the float atomics of the combine cost more than they buy.
-static const bool g_xcd = getenv("GIM_CONV_NO_XCD") == nullptr;  // A/B switch
-// below this many 128x128 output tiles a launch uses 64x64 tiles: 4x the workgroups and a 4x shorter MFMA chain per
-// K step (a workgroup cannot finish faster than its serial K loop: 0.85 us per step at 128x128)
-static const int g_small_tiles = getenv("GIM_CONV_SMALL_TILES") ? atoi(getenv("GIM_CONV_SMALL_TILES")) : 24;
-static int g_force_ksplit = getenv("GIM_CONV_KSPLIT") ? atoi(getenv("GIM_CONV_KSPLIT")) : 0;  // experiments / autotuner
-static int g_force_tile = getenv("GIM_CONV_TILE") ? atoi(getenv("GIM_CONV_TILE")) : 0;
-static int g_wgrad_target = getenv("GIM_WGRAD_TARGET") ? atoi(getenv("GIM_WGRAD_TARGET")) : 0;   // 0: table / default
-static const bool g_use_table = getenv("GIM_CONV_NO_TABLE") == nullptr;
-static const bool g_no_n16 = getenv("GIM_CONV_NO_N16") != nullptr;   // A/B switch
+// Launch configuration.  No process-wide switches: everything a launch depends on is in its gim_conv_shape (prec, tune_*) or in
+// the read-only table below.  (Round 1's environment A/B switches - K step 32, XCD tile orders, channel-group K order, tile /
+// split-K forcing - were removed with the measurements recorded in DESIGN.md section 5 and profiles/r01_*.)
+//
+// Layers whose output tiles do not fill the chip (8x8 and smaller maps, the decoder head, linears) are sliced along K over
+// grid.z.  Measured sweep on MI355X (profiles/r01_ksplit_sweep.txt): best when the launch has about two workgroups per CU
+// (~512 of the 128x128 tiles, proportionally more of the smaller ones); beyond 6 slices the float atomics of the combine cost
+// more than they buy.
+#define GIM_SMALL_TILES 24   // below this many 128x128 output tiles a launch uses 64x64 tiles (4x the workgroups, 4x shorter MFMA chain per K step)
 
 // Launch configurations measured per layer shape on an MI355X (tools/conv_autotune.py writes conv_tune_table.inc):
 // {kind (0 fwd-style, 1 dgrad-style, 2 wgrad; bf16x3 path: 3 fwd, 4 dgrad on transposed weights, 5 wgrad), M, Ca, Cb, Ktot, parity classes,
@@ -1313,33 +1222,16 @@ static const TuneEntry g_tune[] = {
 #include "conv_tune_table.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0}};
 static const TuneEntry* tune_lookup(int kind, int M, int Ca, int Cb, int Ktot, int pc) {
-    if (!g_use_table) return nullptr;
     for (const TuneEntry* e = g_tune; e->kind >= 0; ++e)
         if (e->kind == kind && e->M == M && e->Ca == Ca && e->Cb == Cb && e->Ktot == Ktot && e->pc == pc) return e;
     return nullptr;
 }
 
-// Matrix path of the forward-style fast path: 0 = v_mfma_f32_32x32x2_f32, 1 = bf16x3 (see the kernel).  GIM_CONV_PREC sets the
-// start value; gim_conv_precision(mode) switches at run time and returns the previous mode (mode < 0: query only).
-static int g_prec = getenv("GIM_CONV_PREC") ? atoi(getenv("GIM_CONV_PREC")) : 0;
-extern "C" int gim_conv_precision(int mode) {
-    const int prev = g_prec;
-    if (mode == 0 || mode == 1) g_prec = mode;
-    return prev;
-}
-
-extern "C" int gim_conv_tune_override(int tile_cfg, int ksplit, int wgrad_target) {
-    g_force_tile = tile_cfg; g_force_ksplit = ksplit; g_wgrad_target = wgrad_target;
-    return 0;
-}
-
-// split-K factor: enough workgroups to give every CU several (about 512 of the 128x128 tiles, proportionally more of the
-// smaller ones - measured: profiles/r01_ksplit_sweep.txt, r01_tile_sweep2.txt), never fewer than 8 K-steps per split
-static int plan_ksplit(long long wgs, int nk, int tile_area, int table_ks) {
-    if (g_force_ksplit > 0) return g_force_ksplit > nk ? nk : g_force_ksplit;
-    if (table_ks > 0) return table_ks > nk ? nk : table_ks;
-    static const int scale_small = getenv("GIM_KS_SCALE") ? atoi(getenv("GIM_KS_SCALE")) : 2;  // experiments
-    const long long target = tile_area >= 128 * 128 ? 512 : 512 * scale_small;
+// split-K factor: explicit (shape->tune_ksplit), else the table's, else enough workgroups to give every CU several, never
+// fewer than 8 K-steps per split
+static int plan_ksplit(long long wgs, int nk, int tile_area, int want_ks) {
+    if (want_ks > 0) return want_ks > nk ? nk : want_ks;
+    const long long target = tile_area >= 128 * 128 ? 512 : 1024;
     if (wgs >= target - target / 8 || nk < 16) return 1;
     long long ks = (target + wgs / 2) / wgs;
     if (ks > nk / 8) ks = nk / 8;
@@ -1347,81 +1239,79 @@ static int plan_ksplit(long long wgs, int nk, int tile_area, int table_ks) {
     return ks < 1 ? 1 : (int)ks;
 }
 
-template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int KB, int PREC = 0>
-static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st) {
+// gim_conv_launch_plan: when this thread-local pointer is set, the launchers below record what they WOULD launch
+// ({table row found, BM, BN, split-K | wgrad slices, grid x, y, z, matrix path}) and launch nothing.
+static thread_local int32_t* t_plan_out = nullptr;
+
+template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int PREC = 0>
+static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st, bool table_hit) {
+    constexpr int KB = 16;
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
     const int ncls = p.g.pc ? 4 : 1;
     const int nk = (p.Ktot + KB - 1) / KB;
     p.ksplit = plan_ksplit((long long)gx * gy * ncls, nk, BM * BN, p.tune_ks);
     p.kper = (nk + p.ksplit - 1) / p.ksplit;
     p.ksplit = (nk + p.kper - 1) / p.kper;
-    if (p.ksplit > 1) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
-    p.gx = gx; p.gy = gy;
-    {   // channel-group-major K order where a group is a whole number of K steps and there is more than one tap to sweep
-        static const int korder = getenv("GIM_CONV_KGROUP") ? atoi(getenv("GIM_CONV_KGROUP")) : 0;
-        p.kgrp = (GEN == 0 && korder > 0 && korder % KB == 0 && p.Ca % korder == 0 && p.g.Th * p.g.Tw > 1 && !p.g.ups) ? korder : 0;
+    if (t_plan_out) {
+        const int32_t v[8] = {table_hit ? 1 : 0, BM, BN, p.ksplit, gx, gy, p.ksplit * ncls, PREC};
+        for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
+        return;
     }
-    // XCD-aware tile orders (1: activation tile shared per XCD, 2: weight tile shared per XCD) measured against the plain
-    // order on the bench layers: equal within noise on the large layers, 9 % slower on the small-map 512-channel ones
-    // (profiles/r01_i_xcd_modes.txt), so the plain order is the default; GIM_CONV_XCD_MODE=1|2 selects the others.
-    static const int xcd_mode = getenv("GIM_CONV_XCD_MODE") ? atoi(getenv("GIM_CONV_XCD_MODE")) : 0;
-    p.xcd = (g_xcd && (long long)gx * gy >= 16) ? xcd_mode : 0;
-    const dim3 grid = p.xcd == 1 ? dim3(((gx + 7) / 8) * 8 * gy, 1, p.ksplit * ncls)
-                    : p.xcd == 2 ? dim3(((gx * gy + 7) / 8) * 8, 1, p.ksplit * ncls) : dim3(gx, gy, p.ksplit * ncls);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB, PREC>), grid, dim3(256), 0, st, p);
+    if (p.ksplit > 1 && !p.y_zeroed) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB, PREC>), dim3(gx, gy, p.ksplit * ncls), dim3(256), 0, st, p);
 }
 
 template <int BM, int BN, int TM, int TN, int BMODE, int GEN>
-static void launch_cfg(const ConvP& p, size_t y_elems, hipStream_t st) {
+static void launch_cfg(const ConvP& p, size_t y_elems, hipStream_t st, bool table_hit) {
     if constexpr (BMODE == 0 && GEN == 0 && BN >= 32) {
         if (p.prec == 1) {
-            launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 16, 1>(p, y_elems, st);
+            launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 1>(p, y_elems, st, table_hit);
             return;
         }
     }
-    if constexpr ((GEN & 1) == 0 && BM == 128) {
-        if (p.Ca % 32 == 0 && !g_force_kb16) {
-            launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 32>(p, y_elems, st);
-            return;
-        }
-    }
-    launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 16>(p, y_elems, st);
+    launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN>(p, y_elems, st, table_hit);
 }
 
+// tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K.
+// tune_tile / tune_ks: the caller's explicit choice (gim_conv_shape.tune_tile / tune_ksplit; tune_tile < 0 = heuristics only),
+// else the table row of this shape, else the heuristic.
 template <int BMODE, int GEN>
 static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
-    // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K
     const int M = p.M, Cb = p.Cb;
-    const int force_tile = g_force_tile;
     ConvP pt = p;
-    const TuneEntry* te = (force_tile || g_force_ksplit) ? nullptr : tune_lookup(p.tune_kind, M, p.Ca, Cb, p.Ktot, p.g.pc);
-    pt.tune_ks = te ? te->ks : 0;
-    const int table_tile = te ? te->tile : 0;
-    static const int big_cfg = getenv("GIM_CONV_BIG") ? atoi(getenv("GIM_CONV_BIG")) : 641;       // experiments
-    static const int mid_cfg = getenv("GIM_CONV_MID") ? atoi(getenv("GIM_CONV_MID")) : 1264;
-    const int want = force_tile ? force_tile : table_tile;   // 0: heuristic
+    const bool forced = p.tune_tile != 0 || p.tune_ks > 0;
+    const TuneEntry* te = forced ? nullptr : tune_lookup(p.tune_kind, M, p.Ca, Cb, p.Ktot, p.g.pc);
+    if (te) pt.tune_ks = te->ks;
+    const bool hit = te != nullptr;
+    const int want = p.tune_tile > 0 ? p.tune_tile : (te ? te->tile : 0);   // 0: heuristic
     if (Cb > 64) {
         const long long t128 = (long long)((M + 127) / 128) * ((Cb + 127) / 128) * (p.g.pc ? 4 : 1);
-        int cfg = want ? want : (M <= 64 ? 641 : (t128 < g_small_tiles ? 64 : big_cfg));
-        if (cfg == 641) launch_cfg<64, 128, 1, 2, BMODE, GEN>(pt, y_elems, st);
-        else if (cfg == 1264) launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st);
-        else if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st);
-        else launch_cfg<128, 128, 2, 2, BMODE, GEN>(pt, y_elems, st);
+        int cfg = want ? want : (M <= 64 ? 641 : (t128 < GIM_SMALL_TILES ? 64 : 641));
+        if (cfg == 641) launch_cfg<64, 128, 1, 2, BMODE, GEN>(pt, y_elems, st, hit);
+        else if (cfg == 1264) launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st, hit);
+        else if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st, hit);
+        else launch_cfg<128, 128, 2, 2, BMODE, GEN>(pt, y_elems, st, hit);
     } else if (Cb > 32) {
-        int cfg = (want == 64 || want == 1264) ? want : (M <= 64 ? 64 : mid_cfg);
-        if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st);
-        else launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st);
-    } else if (Cb > 16 || g_no_n16) {
-        launch_cfg<128, 32, 1, 1, BMODE, GEN>(pt, y_elems, st);
+        int cfg = (want == 64 || want == 1264) ? want : (M <= 64 ? 64 : 1264);
+        if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st, hit);
+        else launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st, hit);
+    } else if (Cb > 16) {
+        launch_cfg<128, 32, 1, 1, BMODE, GEN>(pt, y_elems, st, hit);
     } else {
-        launch_cfg<128, 16, 1, 1, BMODE, GEN>(pt, y_elems, st);   // 16x16x4 MFMA tile for <= 16 output channels
+        launch_cfg<128, 16, 1, 1, BMODE, GEN>(pt, y_elems, st, hit);   // 16x16x4 MFMA tile for <= 16 output channels
     }
+}
+
+static int check_prec(const gim_conv_shape* s) {
+    GIM_CHECK_ARG(s->prec == 0 || s->prec == 1, "conv: prec must be 0 (fp32 MFMA) or 1 (bf16x3)");
+    return GIM_OK;
 }
 
 extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias, const float* sigma, const float* residual,
                               float* y, const gim_conv_shape* s, void* stream) {
     int rc = check_shape(s);
     if (rc) return rc;
+    if ((rc = check_prec(s))) return rc;
     GIM_CHECK_ARG(x && w && y, "conv fwd: null pointer");
     {   // operands beyond the 32-bit buffer-offset range: halve the batch (images are independent)
         const size_t xi = (size_t)(s->H >> s->ups) * (s->W >> s->ups) * s->Cin;        // elements per image
@@ -1449,13 +1339,15 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
         p.x_bytes = (unsigned)xb;
     }
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
-    p.prec = g_prec;
-    p.tune_kind = g_prec == 1 ? 3 : 0;
+    p.prec = s->prec;
+    p.tune_kind = s->prec == 1 ? 3 : 0;
+    p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
     if (gen) launch_igemm<0, 1>(p, y_elems, (hipStream_t)stream);
     else launch_igemm<0, 0>(p, y_elems, (hipStream_t)stream);
+    if (t_plan_out) return GIM_OK;
     return gim_check_launch("gim_conv2d_fwd");
 }
 
@@ -1463,6 +1355,7 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
                       const gim_conv_shape* s, void* stream, bool transposed) {
     int rc = check_shape(s);
     if (rc) return rc;
+    if ((rc = check_prec(s))) return rc;
     GIM_CHECK_ARG(dy && w && dx, "conv dgrad: null pointer");
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(mask_x && s->ups && !up_fold), "conv dgrad: mask_x with ups == 1 needs folded weights");
@@ -1498,17 +1391,20 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
     const bool bscalar = (s->Cin % 4) != 0 || ((uintptr_t)w & 15);
     hipStream_t st = (hipStream_t)stream;
     p.tune_kind = 1;
+    p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit;
     if (transposed) {
         // WT[ci][a][b][co]: the weight rows are k-contiguous (k = (tap, co)), i.e. the forward kernel's operand layout
         GIM_CHECK_ARG(!gen && !((uintptr_t)w & 15), "conv dgrad (transposed weights): Cout % 16 == 0 and 16-byte aligned operands required");
         p.Cin_w = s->Cout;
-        p.prec = g_prec;
+        p.prec = s->prec;
         p.tune_kind = 4;
         launch_igemm<0, 0>(p, y_elems, st);
-        return gim_check_launch("gim_conv2d_dgrad_t");
+        if (t_plan_out) return GIM_OK;
+    return gim_check_launch("gim_conv2d_dgrad_t");
     }
     if (gen) { if (bscalar) launch_igemm<1, 3>(p, y_elems, st); else launch_igemm<1, 1>(p, y_elems, st); }
     else     { if (bscalar) launch_igemm<1, 2>(p, y_elems, st); else launch_igemm<1, 0>(p, y_elems, st); }
+    if (t_plan_out) return GIM_OK;
     return gim_check_launch("gim_conv2d_dgrad");
 }
 
@@ -1526,10 +1422,10 @@ extern "C" int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float*
 // stride 2 over the (K+1)^2 folded taps -> slabs in F layout [Cout][KF][KF][Cin].  sub-pixel (ups + wfold), roles
 // swapped: A = leaky_relu(x) [N,H/2,W/2,Cin], B = dy [N,H,W,Cout] gathered with stride 2 -> slabs
 // G[Cin][KF][KF][Cout] with G[ci][ta][tb][co] = dF[co][K-ta][K-tb][ci] (gim_wgrad_finish un-transposes).
-struct WgPlan { int bm, bn, ns, mper, rows, cols, M; };
+struct WgPlan { int bm, bn, ns, mper, rows, cols, M, table_hit; };
 
 static WgPlan wgrad_plan(const gim_conv_shape* s) {
-    WgPlan q;
+    WgPlan q{};
     const bool up_fold = s->ups && s->wfold;
     const int KF = s->wfold ? s->KH + 1 : s->KH;
     q.rows = up_fold ? s->Cin : s->Cout;
@@ -1538,21 +1434,17 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     q.M = (int)M;
     q.bm = q.rows > 64 ? 128 : (q.rows > 32 ? 64 : 32);
     q.bn = (q.bm == 32) ? 128 : (q.cols > 64 ? 128 : 64);
-    if (g_prec == 1) {   // bf16x3 tiles carry 1.9x the LDS of the fp32 ones: caps for experiments (GIM_X3_WG_BM / GIM_X3_WG_BN)
-        static const int cap_m = getenv("GIM_X3_WG_BM") ? atoi(getenv("GIM_X3_WG_BM")) : 128;
-        static const int cap_n = getenv("GIM_X3_WG_BN") ? atoi(getenv("GIM_X3_WG_BN")) : 128;
-        if (q.bm > cap_m && q.bm > 32) q.bm = cap_m;
-        if (q.bn > cap_n && q.bm != 32) q.bn = cap_n;
-    }
     const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
     // about two workgroups per CU in total, and at least 32 K-steps (512 pixels) per workgroup so that the
     // slab write + later slab reduction stay small next to the MFMA work
-    int target = g_wgrad_target;
+    int target = s->tune_wgrad > 0 ? s->tune_wgrad : 0;
+    if (!target && s->tune_tile < 0) target = 1024;   // heuristics only
     if (!target) {
         const int pcw = (s->pool ? 1 : 0) + (up_fold ? 2 : 0);
-        const TuneEntry* te = g_prec == 1 ? tune_lookup(5, (int)M, q.rows, q.cols, s->KH, pcw) : nullptr;   // bf16x3 rows first
+        const TuneEntry* te = s->prec == 1 ? tune_lookup(5, (int)M, q.rows, q.cols, s->KH, pcw) : nullptr;   // bf16x3 rows first
         if (!te) te = tune_lookup(2, (int)M, q.rows, q.cols, s->KH, pcw);
         target = te ? te->ks : 1024;
+        q.table_hit = te ? 1 : 0;
     }
     long long S = (target + tiles - 1) / tiles;
     const long long maxS = (M + 511) / 512;
@@ -1566,14 +1458,13 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     return q;
 }
 
-// Default: the pixel slices of one weight gradient are combined with float atomics in the kernel epilogue (the
-// caller sees ONE slab; no separate reduce pass - at 16 episodes per GPU that pass cost 7 % of the step).  The sum
-// order then varies from run to run in the last bits.  GIM_WGRAD_SLABS=1 restores the deterministic slab form.
-static const bool g_wgrad_atomic = getenv("GIM_WGRAD_SLABS") == nullptr;
-
+// The pixel slices of one weight gradient are combined either with float atomics in the kernel epilogue (n_slabs = 1: the
+// caller sees ONE slab, no separate reduce pass - at 16 episodes per GPU that pass cost 7 % of the step; the sum order then
+// varies from run to run in the last bits) or, deterministically, as gim_conv2d_wgrad_slabs(shape) separate slabs that
+// gim_wgrad_finish adds up in a fixed order.  The caller chooses per call through n_slabs.
 extern "C" int gim_conv2d_wgrad_slabs(const gim_conv_shape* s) {
     if (check_shape(s)) return GIM_E_BADARG;
-    return g_wgrad_atomic ? 1 : wgrad_plan(s).ns;
+    return wgrad_plan(s).ns;
 }
 
 template <bool FASTB>
@@ -1600,10 +1491,11 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
                       void* stream, bool prezeroed) {
     int rc = check_shape(s);
     if (rc) return rc;
+    if ((rc = check_prec(s))) return rc;
     GIM_CHECK_ARG(dy && x && slabs, "conv wgrad: null pointer");
     const WgPlan q = wgrad_plan(s);
-    const bool atomic = prezeroed ? true : (g_wgrad_atomic && q.ns > 1);
-    if (!prezeroed) GIM_CHECK_ARG(n_slabs == (g_wgrad_atomic ? 1 : q.ns), "conv wgrad: n_slabs must equal gim_conv2d_wgrad_slabs(shape)");
+    const bool atomic = prezeroed ? true : (n_slabs == 1 && q.ns > 1);
+    if (!prezeroed) GIM_CHECK_ARG(n_slabs == 1 || n_slabs == q.ns, "conv wgrad: n_slabs must be 1 (atomic combine) or gim_conv2d_wgrad_slabs(shape)");
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(up_fold && bias_slabs), "conv wgrad: the sub-pixel form does not produce the bias gradient (use gim_colsum)");
     WgP p{};
@@ -1624,15 +1516,19 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
         GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv wgrad: gathered tensor larger than 2 GiB (32-bit buffer offsets): split the batch");
         p.x_bytes = (unsigned)xb;
     }
-    if (atomic && !prezeroed) {
+    if (atomic && !prezeroed && !t_plan_out) {
         (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
         if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
     }
     dim3 g((q.cols + q.bn - 1) / q.bn, (q.rows + q.bm - 1) / q.bm, q.ns);
+    if (t_plan_out) {
+        const int32_t v[8] = {q.table_hit, q.bm, q.bn, q.ns, (int32_t)g.x, (int32_t)g.y, (int32_t)g.z, s->prec};
+        for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
+        return GIM_OK;
+    }
     const bool vec = (s->Cin % 4 == 0) && (s->Cout % 4 == 0) && !(((uintptr_t)dy | (uintptr_t)x) & 15);
     const bool fastb = vec && p.g.ups == 0 && ((p.g.H * p.g.W) & (BK - 1)) == 0;   // a K step stays inside one image
-    static const bool x3_wgrad = getenv("GIM_X3_NO_WGRAD") == nullptr;   // A/B switch
-    if (g_prec == 1 && vec && x3_wgrad) {
+    if (s->prec == 1 && vec) {
         if (fastb) launch_wgrad_x3<true>(p, q.bm, q.bn, g, (hipStream_t)stream);
         else launch_wgrad_x3<false>(p, q.bm, q.bn, g, (hipStream_t)stream);
     }
@@ -1660,4 +1556,22 @@ extern "C" int gim_conv2d_wgrad_acc(const float* dy, const float* x, float* acc,
         }
     }
     return wgrad_impl(dy, x, acc, bias_acc, 1, s, stream, true);
+}
+
+// The launch a conv entry point would make for `shape`, without launching anything (tests, tools/conv_autotune.py).
+//   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
+//   out[8] = {1 if a row of the compiled-in launch table matched this shape, tile rows BM, tile columns BN,
+//             split-K factor (wgrad: pixel slices), grid x, grid y, grid z, matrix path the kernel runs (0 fp32 MFMA, 1 bf16x3)}
+extern "C" int gim_conv_launch_plan(const gim_conv_shape* s, int kind, int32_t* out) {
+    GIM_CHECK_ARG(s && out && kind >= 0 && kind <= 3, "conv_launch_plan: bad args");
+    float* const fake = reinterpret_cast<float*>(uintptr_t(4096));   // aligned, never dereferenced: nothing is launched
+    for (int i = 0; i < 8; ++i) out[i] = -1;
+    t_plan_out = out;
+    int rc;
+    if (kind == 0) rc = gim_conv2d_fwd(fake, fake, nullptr, nullptr, nullptr, fake, s, nullptr);
+    else if (kind == 1) rc = gim_conv2d_dgrad(fake, fake, nullptr, nullptr, fake, s, nullptr);
+    else if (kind == 2) rc = gim_conv2d_dgrad_t(fake, fake, nullptr, nullptr, fake, s, nullptr);
+    else rc = gim_conv2d_wgrad_acc(fake, fake, fake, nullptr, s, nullptr);
+    t_plan_out = nullptr;
+    return rc;
 }

@@ -45,6 +45,52 @@ def _second_order():
     return True
 
 
+# Executed-work accounting (bench.py, tools/): inside `count_flops()` every convolution / linear / batched-GEMM launch adds
+# the multiply-adds its kernel EXECUTES (the pool / sub-pixel folds run (K+1)^2 taps at a quarter of the pixels, not the
+# K^2 full-resolution taps of the unfused reference op) to a Counter keyed by (kind, shape).  Off (None) otherwise.
+_FLOPS = None
+
+
+class count_flops:
+    """with ops.count_flops() as c: ...   ->  c[(kind, cfg)] = [launches, executed FLOPs per launch]; kinds fwd / dgrad / wgrad / bgemm;
+    cfg = (N, H, W, Cin, Cout, KH, ups, pool, fold) for convolutions and linears (H = W = KH = 1), (batch, M, N, K) for bgemm."""
+
+    def __enter__(self):
+        global _FLOPS
+        self.prev = _FLOPS
+        _FLOPS = {}
+        return _FLOPS
+
+    def __exit__(self, *exc):
+        global _FLOPS
+        _FLOPS = self.prev
+
+
+def conv_executed_flops(N, H, W, Cin, Cout, KH, ups, pool, fold):
+    """2 * MACs one forward (= one dgrad = one wgrad) launch of this convolution executes.  (H, W) is the resolution the
+    unfused conv would run at (after the nearest upsample, before the average pool)."""
+    if fold and pool:        # ONE stride-2 conv, (K+1)^2 taps, on the pooled grid
+        return 2.0 * N * (H >> 1) * (W >> 1) * Cin * Cout * (KH + 1) ** 2
+    if fold and ups:         # 4 parity classes on the low-resolution grid, ((K+1)/2)^2 taps each
+        return 2.0 * N * H * W * Cin * Cout * ((KH + 1) // 2) ** 2
+    return 2.0 * N * H * W * Cin * Cout * KH * KH
+
+
+def conv_algorithmic_flops(N, H, W, Cin, Cout, KH, *_):
+    """2 * MACs of the unfused reference op (F.conv2d at the full resolution): the SURVEY.md 8(d) convention."""
+    return 2.0 * N * H * W * Cin * Cout * KH * KH
+
+
+def _note_conv(kind, cfg):
+    N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
+    key = (kind, (N, H, W, Cin, Cout, KH, int(ups), int(bool(pool)), int(fold)))
+    ent = _FLOPS.get(key)
+    if ent is None:
+        _FLOPS[key] = [1, conv_executed_flops(*key[1])]
+    else:
+        ent[0] += 1
+
+
 def _stream():
     """Raw handle of the caller's current HIP stream.  (torch.cuda.current_stream() builds a Stream object through several
     layers of Python, ~4 us; with ~1400 kernel calls per step that was 6 ms of the ~35 ms the host needs per step.)"""
@@ -73,8 +119,28 @@ def weight_phys(w):
     return wp if wp.is_contiguous() else wp.contiguous()
 
 
+# Matrix path of the conv / linear contractions: 0 = fp32 MFMA, 1 = bf16x3 (include/gim_hip.h, gim_conv_shape.prec).  A host-side
+# default that every launch copies into its shape struct (the library itself keeps no state); GIM_CONV_PREC sets the start value.
+_CONV_PREC = [1 if os.environ.get("GIM_CONV_PREC") == "1" else 0]
+# Deterministic weight-gradient combine (slabs + fixed-order reduce) instead of float atomics, for the non-queued path
+_WGRAD_SLABS = os.environ.get("GIM_WGRAD_SLABS") is not None
+
+
+def conv_precision():
+    return _CONV_PREC[0]
+
+
+def set_conv_precision(mode):
+    """Select the matrix path of all following conv / linear launches of this process; returns the previous mode."""
+    if mode not in (0, 1):
+        raise ValueError("conv precision must be 0 (fp32 MFMA) or 1 (bf16x3)")
+    prev = _CONV_PREC[0]
+    _CONV_PREC[0] = mode
+    return prev
+
+
 def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
-    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups)
+    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, _CONV_PREC[0], 0, 0, 0)
 
 
 # --------------------------------------------------------------------------------------------
@@ -302,6 +368,8 @@ class ConvFn(Function):
         ctx.save_for_backward(x, w, sigma, u_s, v_s, wf if fold else None, bias)
         ctx.cfg = (N, H, W, Cin, Cout, KH, ups, pre_slope, bias is not None, res is not None, bool(pool), fold, bool(res_ups))
         ctx.guard = guard
+        if _FLOPS is not None:
+            _note_conv("fwd", ctx.cfg)
         return y
 
     @staticmethod
@@ -343,7 +411,6 @@ class ConvFn(Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
-_DGRAD_T_ALWAYS = os.environ.get("GIM_DGRAD_T") is not None   # A/B switch: transposed-weight dgrad on the fp32 MFMA path too (measured slower: 341 vs 352 episodes/s)
 _WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
 
 
@@ -370,13 +437,15 @@ def _transposed(lib, w, wk, Cout, Cin, KF):
 
 def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
     """dx = lrelu'(x) * dgrad(dy, w) / sigma  (through the pool / sub-pixel folds when the forward used them).
-    With the bf16x3 matrix path selected (gim_conv_precision) and the parameter `w` given, layers with Cout % 16 == 0 run
+    With the bf16x3 matrix path selected (sh.prec == 1, ops.set_conv_precision) and the parameter `w` given, layers with Cout % 16 == 0 run
     the k-contiguous kernel on cached transposed weights (gim_conv2d_dgrad_t)."""
     N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
+    if _FLOPS is not None:
+        _note_conv("dgrad", cfg)
     mask = x if pre_slope != 1.0 else None
     dx = torch.empty_like(x)
     wk = wf if fold else wp
-    if w is not None and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold) and (_DGRAD_T_ALWAYS or lib.gim_conv_precision(-1) == 1):
+    if w is not None and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold) and sh.prec == 1:
         wt = _transposed(lib, w, wk, Cout, Cin, KH + 1 if fold else KH)
         check(lib.gim_conv2d_dgrad_t(_p(dy), _p(wt), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad_t")
         return dx
@@ -392,12 +461,16 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
 def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
     """(dw, db) of one convolution; either may come back None because it was ADDED into the parameter's .grad."""
     N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
+    if _FLOPS is not None:
+        _note_conv("wgrad", cfg)
     dev = dy.device
     dw = db = None
     Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
-    ns = lib.gim_conv2d_wgrad_slabs(sh)
-    if ns <= 0:
-        check(ns, "conv2d_wgrad_slabs")
+    ns = 1   # pixel slices combined with float atomics; GIM_WGRAD_SLABS=1: deterministic slabs (non-queued path only)
+    if _WGRAD_SLABS:
+        ns = lib.gim_conv2d_wgrad_slabs(sh)
+        if ns <= 0:
+            check(ns, "conv2d_wgrad_slabs")
     K = KH * KH * Cin
     KFF = (KH + 1) * (KH + 1) * Cin if fold else K
     dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
@@ -486,6 +559,8 @@ class ConvDgradFn(Function):
         if ctx.needs_input_grad[0]:
             g_dy = torch.empty_like(dy)
             check(lib.gim_conv2d_fwd(_p(gm), _p(wf if fold else wp), None, _p(sigma), None, _p(g_dy), sh, st), "conv2d_fwd")
+            if _FLOPS is not None:
+                _note_conv("fwd", lin)
         if ctx.needs_input_grad[1]:
             g_w, _ = _conv_wgrad(lib, dy, gm, w, wp, None, sigma, u_s, v_s, sh, lin, False, st)
         return g_dy, g_w, None, None, None, None, None, None
@@ -784,6 +859,9 @@ class ToNCHWFn(Function):
 # self-attention core
 # --------------------------------------------------------------------------------------------
 def _bgemm(A, B, C, batch, M, N, K, sA, sB):
+    if _FLOPS is not None:
+        ent = _FLOPS.setdefault(("bgemm", (batch, M, N, K)), [0, 2.0 * batch * M * N * K])
+        ent[0] += 1
     check(_lib.load().gim_bgemm(_p(A), _p(B), _p(C), batch, M, N, K, sA[0], sA[1], sA[2], sB[0], sB[1], sB[2], _stream()), "bgemm")
 
 

@@ -1,4 +1,4 @@
-"""GPU parity of the bf16x3 matrix path (gim_conv_precision(1)): the forward-style contraction and - through cached
+"""GPU parity of the bf16x3 matrix path (gim_conv_shape.prec = 1, selected host-side by ops.set_conv_precision(1)): the forward-style contraction and - through cached
 transposed weights, gim_conv2d_dgrad_t - the input gradient run on the bf16 matrix pipe with every fp32 operand split exactly
 into three bf16 numbers.  The SAME checks and the SAME tolerances as the fp32-MFMA path (operators 3e-5 against fp64, losses /
 logits 1e-3 against the reference goldens): the tests of test_gpu_ops.py / test_gpu_models.py are re-run with the path switched on.
@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def bf16x3():
-    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib, ops
     lib = _lib.load()
-    prev = lib.gim_conv_precision(1)
-    assert lib.gim_conv_precision(-1) == 1
+    prev = ops.set_conv_precision(1)
+    assert ops.conv_precision() == 1
     yield lib
-    lib.gim_conv_precision(prev)
+    ops.set_conv_precision(prev)
 
 
 FAST = [c for c in to.CONV_CASES if c[1] % 16 == 0]          # the k-contiguous fast path (Cin % 16 == 0)
@@ -51,7 +51,8 @@ def test_dgrad_on_transposed_weights_equals_dgrad(bf16x3, N, Cin, Cout, K, H, po
     g = torch.Generator(device=dev).manual_seed(5)
     fold = 1 if (pool or ups) else 0
     KF = K + 1 if fold else K
-    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, 0.2, pool, fold, 0)
+    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, 0.2, pool, fold, 0, 0)        # k-major weights, fp32 MFMA
+    sh_t = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, 0.2, pool, fold, 0, 1)      # transposed weights, bf16x3
     w = torch.randn(Cout, KF, KF, Cin, device=dev, generator=g) * 0.05
     dy = torch.randn(N, H >> pool, H >> pool, Cout, device=dev, generator=g)
     lo = 1 if (ups and fold) else 0
@@ -63,11 +64,14 @@ def test_dgrad_on_transposed_weights_equals_dgrad(bf16x3, N, Cin, Cout, K, H, po
     _lib.check(lib.gim_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), sigma.data_ptr(), x.data_ptr(), d0.data_ptr(), sh, st), "dgrad")
     _lib.check(lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st), "transpose")
     assert torch.equal(wt.view(Cin, KF, KF, Cout), w.permute(3, 1, 2, 0).contiguous())
-    _lib.check(lib.gim_conv2d_dgrad_t(dy.data_ptr(), wt.data_ptr(), sigma.data_ptr(), x.data_ptr(), d1.data_ptr(), sh, st), "dgrad_t")
+    _lib.check(lib.gim_conv2d_dgrad_t(dy.data_ptr(), wt.data_ptr(), sigma.data_ptr(), x.data_ptr(), d1.data_ptr(), sh_t, st), "dgrad_t")
     err = float((d0 - d1).abs().max() / d0.abs().max())
     assert err < 2e-6, err
     # Cout not a multiple of 16 is refused, not mis-computed
-    bad = _lib.GimConvShape(N, H, H, Cin, 24, K, 0, 0.2, 0, 0, 0)
+    bad = _lib.GimConvShape(N, H, H, Cin, 24, K, 0, 0.2, 0, 0, 0, 1)
+    assert lib.gim_conv2d_dgrad_t(dy.data_ptr(), wt.data_ptr(), None, None, d1.data_ptr(), bad, st) != 0
+    # an unknown matrix path is refused as well
+    bad = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, 0.2, pool, fold, 0, 7)
     assert lib.gim_conv2d_dgrad_t(dy.data_ptr(), wt.data_ptr(), None, None, d1.data_ptr(), bad, st) != 0
 
 
@@ -97,12 +101,11 @@ def test_loss_curve_vs_oracle():
     matrix paths stay at 1e-7 for seven iterations, the CPU fp32 run is at 1e-4 by then); six iterations leave a wide margin."""
     import tempfile
     import optimalstrategiesagainstgenerativeattacks_amd as G
-    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
     from oracle import gim_oracle as go
     from tests.helpers import episode, filled_sd, load_keys, relerr
     from tests.test_gpu_models import _product_models, dev
-    lib = _lib.load()
-    prev = lib.gim_conv_precision(-1)
+    prev = ops.conv_precision()
     try:
         tag, cfg = "curve", "16_1_32"
         B, m, n, k, c, s, d = 4, 1, 3, 4, 1, 16, 32
@@ -118,9 +121,9 @@ def test_loss_curve_vs_oracle():
             leaked, real, si, z = episode("%s%d" % (tag, it), B, m, n, k, c, s, d)
             g_o, d_o = otr.step(leaked, real, si, z)
             for mode, trainer in prods:
-                lib.gim_conv_precision(mode)
+                ops.set_conv_precision(mode)
                 gi, di = G.gim_step(trainer, *[t.float().to(dev()) for t in (leaked, real, si)], z=z.float().to(dev()))
                 eg, ed = relerr(gi[0], g_o[0].mean()), relerr(di[0], d_o[0].mean())
                 assert eg < 1e-3 and ed < 1e-3, (("fp32 MFMA", "bf16x3")[mode], it, eg, ed)
     finally:
-        lib.gim_conv_precision(prev)
+        ops.set_conv_precision(prev)

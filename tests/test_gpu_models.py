@@ -162,10 +162,43 @@ def test_config5_shape_128_vs_reference_golden():
     _check_nets("vox128_f64", "128_3_512", 1e-3, 5e-2)
 
 
+def _noise_walk(opt, params, n_updates, lr):
+    """Per parameter: how far Adam(beta1 = 0) can random-walk it on rounding noise alone.  Such an update moves EVERY element by
+    ~lr whatever the gradient's size (m / sqrt(v) = sign(g)), so a tensor whose gradient is mathematically zero - a conv bias in
+    front of InstanceNorm / AdaIN, the attention's f-bias - follows the SIGN of rounding noise: +-lr per element per update, in
+    fp64 and fp32 alike but not alike.  Those tensors are recognised by their own second moments (sqrt(v) at noise level)."""
+    walk = {}
+    for name, p in params:
+        st = opt.state.get(p)
+        if st is None or "exp_avg_sq" not in st:
+            walk[name] = None      # never updated (unused img_att.* parameters)
+            continue
+        walk[name] = n_updates * lr * p.numel() ** 0.5 if float(st["exp_avg_sq"].sqrt().mean()) < 1e-6 else 0.0
+    return walk
+
+
+def _assert_final_state(mod, ref, walk, what):
+    """Per-tensor sum and L2 norm of the state dict after the protocol against the reference's (fixture meta.*_final):
+    relative 1e-4 (norm) / the matching bound on the sum; noise-walk tensors (see _noise_walk) within their walk."""
+    sd = mod.state_dict()
+    assert list(sd.keys()) == list(ref.keys()), what
+    bad = []
+    for k_, (s_ref, n_ref) in ref.items():
+        t = sd[k_].detach().double()
+        w = walk.get(k_) or 0.0
+        n = t.numel() ** 0.5
+        if abs(float(t.norm()) - n_ref) > 1e-4 * n_ref + w or abs(float(t.sum()) - s_ref) > 1e-4 * n_ref * n + w * n:
+            bad.append((k_, float(t.norm()), n_ref, float(t.sum()), s_ref, w))
+    assert not bad, "%s: %d/%d tensors off the reference's final state, first: %s" % (what, len(bad), len(ref), bad[:4])
+
+
 @pytest.mark.parametrize("tag", ["reg0", "reg10", "nau2"])
 def test_trainer_protocol_vs_reference_golden(tag):
     """Real step protocol (im_train_step / im_eval_step + au_train_step, MultiStepLR, FusedAdam) for consecutive
-    iterations from a conditioned state, against the reference's own loop (fp64)."""
+    iterations from a conditioned state, against the reference's own loop (fp64): every returned tensor of every iteration,
+    the learning rates and global step, then the eval-mode pass, and the state the protocol leaves behind - every parameter
+    and spectral-norm u / v buffer of both agents, Adam's step counts and second moments (SURVEY.md 8(c).3;
+    training/gim_img_training.py:76-95,157-183, training/gim_img_trainer.py:96-149)."""
     import optimalstrategiesagainstgenerativeattacks_amd as G
     import tempfile
     g = load_npz("trainer_%s.npz" % tag)
@@ -178,6 +211,7 @@ def test_trainer_protocol_vs_reference_golden(tag):
                              reg_param=c["reg_param"])
     trainer = G.DataParallelMock(tr)
     n_steps = len(meta["meta"]["lrs"])
+    n_im_updates = 0
     for it in range(n_steps):
         leaked, real, si, z = [t.float().to(dev()) for t in
                                episode("%s/it%d" % (tag, it), c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
@@ -188,20 +222,45 @@ def test_trainer_protocol_vs_reference_golden(tag):
         assert tr.global_step == lrs[3]
         if (tr.global_step + 1) % c["n_au_steps"] == 0:
             gres = G.im_train_step(trainer, leaked, si, z=z)
+            n_im_updates += 1
         else:
             gres = G.im_eval_step(trainer, leaked, si, z=z)
         dres = G.au_train_step(trainer, real, gres[1], si)
-        # Adam with beta1 = 0 moves every weight by ~lr per step whatever the gradient size, so fp32 rounding of
-        # near-zero gradients shows up after the first update: 1e-3 on step 0, looser afterwards
-        tol = 1e-3 if it == 0 else 2e-2
+        # north_star: 1e-3 on losses / logits.  Measured deviation of this path from the fp64 run stays at 1e-7 for seven
+        # iterations (profiles/r01_k_loss_curve_deviation.txt): 1e-4 on every iteration leaves three orders of margin.
+        tol = 1e-4
         assert relerr(gres[0], g["it%d/g_loss" % it]) < tol, (it, "g_loss")
         assert relerr(gres[2], g["it%d/g_out" % it]) < tol, (it, "g_out")
         assert relerr(gres[1], g["it%d/fake" % it]) < tol, (it, "fake")
         for i, nm in enumerate(["loss", "loss_real", "loss_fake", "reg", "out_real", "out_fake"]):
             ref = g["it%d/d_%s" % (it, nm)]
             assert relerr(dres[i], ref) < tol or float(np.abs(ref).max()) == 0.0, (it, nm)
-    assert meta["meta"]["au_opt_n_state"] == len(tr.authenticator_opt.state_dict()["state"])
-    assert len(tr.impersonator_opt.param_groups) == meta["meta"]["im_opt_n_groups"]
+        assert (dres[6].cpu().numpy() == g["it%d/d_pred_real" % it]).all() and (dres[7].cpu().numpy() == g["it%d/d_pred_fake" % it]).all()
+    # eval-mode pass afterwards: no power iteration, no gradients (im_eval_step / au_eval_step)
+    state_before = {k_: v.clone() for k_, v in list(au.state_dict().items()) + list(im.state_dict().items())}
+    leaked, real, si, z = [t.float().to(dev()) for t in episode(tag + "/eval", c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
+    ge = G.im_eval_step(trainer, leaked, si, z=z)
+    de = G.au_eval_step(trainer, real, ge[1], si)
+    assert relerr(ge[0], g["eval/g_loss"]) < 1e-4 and relerr(ge[2], g["eval/g_out"]) < 1e-4
+    assert relerr(de[0], g["eval/d_loss"]) < 1e-4
+    assert relerr(de[4], g["eval/d_out_real"]) < 1e-4 and relerr(de[5], g["eval/d_out_fake"]) < 1e-4
+    for k_, v in list(au.state_dict().items()) + list(im.state_dict().items()):
+        assert torch.equal(v, state_before[k_]), ("the eval pass changed state", k_)
+    # the state the protocol leaves behind
+    m_ = meta["meta"]
+    au_walk = _noise_walk(tr.authenticator_opt, au.named_parameters(), n_steps, c["au_lr"])
+    im_walk = _noise_walk(tr.impersonator_opt, im.named_parameters(), n_im_updates, c["im_lr"])
+    _assert_final_state(au, m_["au_final"], au_walk, "authenticator")
+    _assert_final_state(im, m_["im_final"], im_walk, "impersonator")
+    osd = tr.authenticator_opt.state_dict()
+    assert sorted({int(v["step"]) for v in osd["state"].values()}) == m_["au_opt_steps"]
+    assert m_["au_opt_n_state"] == len(osd["state"])
+    # (the reference's impersonator optimizer holds state only for parameters that ever had a gradient; FusedAdam publishes
+    # zero moments for the unused img_att.* too: their count is the reference's plus those)
+    assert len(tr.impersonator_opt.state_dict()["state"]) >= m_["im_opt_n_state"]
+    assert len(tr.impersonator_opt.param_groups) == m_["im_opt_n_groups"]
+    first = tr.authenticator_opt.state[next(iter(au.parameters()))]
+    assert abs(float(first["exp_avg_sq"].double().norm()) - m_["au_opt_first_v_norm"]) < 1e-3 * m_["au_opt_first_v_norm"]
 
 
 @pytest.mark.parametrize("reg_param", [0.0, 10.0])
@@ -215,10 +274,11 @@ def test_product_vs_oracle_fp32_step_and_state(reg_param):
     keys = load_keys(cfg)
     au_o = filled_sd(keys["au"], tag + "/au/")
     im_o = filled_sd(keys["im"], tag + "/im/")
-    otr = go.OracleTrainer(au_o, im_o, n, 1e-3, 1e-3, 1e-4, reg_param=reg_param)
+    lrs = {"au": 1e-3, "im": 1e-3}
+    otr = go.OracleTrainer(au_o, im_o, n, lrs["au"], lrs["im"], 1e-4, reg_param=reg_param)
     au, im = _product_models(tag, cfg)
     with tempfile.TemporaryDirectory() as td:
-        tr = G.GIMImgTrainer(td, m, n, k, au, im, 1e-3, 1e-3, 1e-4, reg_param=reg_param)
+        tr = G.GIMImgTrainer(td, m, n, k, au, im, lrs["au"], lrs["im"], 1e-4, reg_param=reg_param)
     trainer = G.DataParallelMock(tr)
     leaked, real, si, z = episode(tag, B, m, n, k, c, s, d)
     (g_o, d_o) = otr.step(leaked, real, si, z)
@@ -227,20 +287,30 @@ def test_product_vs_oracle_fp32_step_and_state(reg_param):
     assert relerr(di[0], d_o[0].mean()) < 1e-3 and relerr(di[4], d_o[4].mean()) < 1e-3
     if reg_param > 0:
         assert float(d_o[3].mean()) > 0 and relerr(di[3], d_o[3].mean()) < 1e-3
-    # parameters moved by ~lr each (beta1 = 0): compare the UPDATE direction where the gradient is not noise
-    bad = []
+    # One Adam update with beta1 = 0 moves an element by lr * g / (|g| + eps): by ~lr * sign(g) wherever the gradient is above
+    # rounding noise.  So compare ELEMENTWISE where the oracle's gradient element is not negligible inside its tensor (>= 1e-3
+    # of the tensor's rms; |g| is recovered from the oracle's second moment v = (1 - beta2) g^2): there the product's new value
+    # must be the oracle's to a small fraction of one step.  No tensor is exempted.
+    beta2 = 0.99
+    gmax = max(float(st["v"].max()) for opt in (otr.au_opt, otr.im_opt) for st in opt.state.values()) ** 0.5 / (1 - beta2) ** 0.5
+    checked = 0
     for name, mod, sd_o, opt_o in (("au", au, au_o, otr.au_opt), ("im", im, im_o, otr.im_opt)):
         for kk, p in mod.named_parameters():
             if kk not in opt_o.state:
                 continue
-            gn = float(opt_o.state[kk]["v"].sqrt().mean())
-            if gn < 1e-6:
-                continue
-            if relerr(p, sd_o[kk]) > 2e-3:
-                bad.append((name, kk, relerr(p, sd_o[kk])))
+            gabs = (opt_o.state[kk]["v"] / (1 - beta2)).sqrt()
+            rms = float(gabs.square().mean().sqrt())
+            if rms < 1e-9 * gmax:
+                continue      # mathematically zero gradient (a conv bias in front of a norm layer): pure rounding noise
+            lr = 1e-4 if kk.startswith("env_noise_mapper") and name == "im" else lrs[name]
+            mask = gabs > 1e-3 * rms
+            diff = (p.detach().double().cpu() - sd_o[kk].detach()).abs()[mask]
+            off = float((diff > 0.05 * lr).double().mean())
+            assert off < 1e-3, (name, kk, "share of elements whose update differs from the oracle's", off, float(diff.max()))
+            checked += int(mask.sum())
         for kk, b in mod.named_buffers():
             assert relerr(b, sd_o[kk]) < 1e-3, (name, kk)
-    assert len(bad) <= 3, bad[:10]
+    assert checked > 100000
 
 
 def test_graphed_step_equals_eager_step():

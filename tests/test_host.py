@@ -258,3 +258,59 @@ def test_roc_auc_matches_sklearn():
         assert abs(roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12
     acc, acc_f, acc_r = comp_acc(torch.tensor([1, 1, 0, 1]), torch.tensor([0, 1, 0, 0]))
     assert float(acc_r) == 0.75 and float(acc_f) == 0.75 and float(acc) == 0.75
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus N launches itself; the library keeps no process-wide state
+# ---------------------------------------------------------------------------------------------------
+def test_bench_self_launch_dry_run_gloo_world2():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) starts two ranks of itself, which rendezvous
+    (gloo here, RCCL on the GPU node), all-reduce once, and rank 0's ONE JSON line comes out of the parent; the parent's return
+    code is the worst rank's.  --dry-run stops before anything touches a GPU."""
+    import json
+    import subprocess
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GIM_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo"
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["config"]["global_batch"] == 32
+    # a launcher's environment is used as given: WORLD_SIZE that disagrees with --gpus is refused, and the failure propagates
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in bad.stderr
+
+
+def test_conv_shape_struct_matches_the_header():
+    """The ctypes mirror of gim_conv_shape has the header's fields in the header's order (matrix path and launch overrides are
+    per-call fields: the library has no precision / tuning globals)."""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    header = open(os.path.join(ROOT, "include", "gim_hip.h")).read()
+    body = re.search(r"typedef struct \{([^}]*)\} gim_conv_shape;", header).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            fields += [f.strip() for f in decl.split(None, 1)[1].split(",")]
+    assert fields == [f for f, _ in _lib.GimConvShape._fields_], fields
+    assert ctypes.sizeof(_lib.GimConvShape) == 4 * len(fields)
+    assert "gim_conv_precision" not in header and "gim_conv_tune_override" not in header
+
+
+def test_library_sources_read_no_environment_and_keep_no_mutable_globals():
+    """include/gim_hip.h promises: no environment variables, no mutable process-wide state.  Checked on the sources: no getenv,
+    and every namespace-scope `static` object is const / constexpr or thread_local (the error string, the plan-recording hook)."""
+    csrc = os.path.join(ROOT, "optimalstrategiesagainstgenerativeattacks_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        assert "getenv" not in src, f
+        assert "GIM_DBG" not in src, f
+        for mt in re.finditer(r"^static\s+(?!inline|const|constexpr|thread_local|__device__|__global__|void|int\s+\w+\(|bool\s+\w+\(|Geo\s+\w+\(|"
+                              r"WgPlan\s+\w+\(|size_t\s+\w+\(|float\s+\w+\(|long\s+long\s+\w+\()([^;{(]*)[;=]", src, re.M):
+            raise AssertionError("%s: mutable file-scope static: %s" % (f, mt.group(0)))

@@ -39,12 +39,12 @@ for (N, Cin, Cout, K, H, pool) in SHAPES:
         (y * r).sum().backward()
         res = {}
         for mode in (0, 1):
-            lib.gim_conv_precision(mode)
+            ops.set_conv_precision(mode)
             xg = x.detach().permute(0, 2, 3, 1).contiguous().float().to(dev).requires_grad_()
             wg = w.detach().float().to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
             yg = ops.conv2d(xg, wg, None, None, None, None, None, 0, 1.0, pool=bool(pool))
             (yg * r.permute(0, 2, 3, 1).contiguous().float().to(dev)).sum().backward()
             res[mode] = (err(yg.detach().permute(0, 3, 1, 2), y.detach()), err(xg.grad.permute(0, 3, 1, 2), x.grad), err(wg.grad, w.grad))
-        lib.gim_conv_precision(0)
+        ops.set_conv_precision(0)
         for i, name in enumerate(("fwd", "dgrad", "wgrad")):
             print("%-34s %-9s | %-5s %.2e / %.2e     | %.2e / %.2e" % ((N, Cin, Cout, K, H, int(pool)), kind, name, res[0][i][0], res[0][i][1], res[1][i][0], res[1][i][1]), flush=True)

@@ -75,7 +75,11 @@ def main():
             continue   # generic-K layers (3 / 6 channels): heuristics only
         n_dx = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dx)
         n_dw = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dw)
-        sh = _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0)
+        x3 = ops.conv_precision() == 1      # bf16x3 matrix path: its own table rows (kinds 3, 4, 5)
+
+        def shape(tile=-1, ks=0, tg=0):   # tile -1: heuristics only (ignore the rows already in the compiled-in table)
+            return _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0, 1 if x3 else 0, tile, ks, tg)
+        sh = shape()
         x = torch.randn(N, H >> ups, W >> ups, Cin, device=dev)
         KF = KH + 1 if fold else KH
         w = torch.randn(Cout, KF, KF, Cin, device=dev) * 0.05
@@ -99,8 +103,7 @@ def main():
         cols = KF * KF * (Cout if up_fold else Cin)
         Mw = N * (H >> (1 if fold else 0)) * (W >> (1 if fold else 0))
         keys["wgrad"] = (2, Mw, rows, cols, KH, (1 if pool else 0) + (2 if up_fold else 0))
-        x3 = lib.gim_conv_precision(-1) == 1      # bf16x3 matrix path: its own table rows (kinds 3, 4)
-        dgrad_fn = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
+        dgrad_fn = lambda sh_: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh_, st)   # noqa: E731
         if x3:
             keys["fwd"] = (3,) + keys["fwd"][1:]
             if Cin % 4 == 0 and Cout % 4 == 0:
@@ -109,16 +112,15 @@ def main():
                 wt = torch.empty(Cin * KF * KF * Cout, device=dev)
                 lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
                 keys["dgrad"] = (4,) + keys["dgrad"][1:]
-                dgrad_fn = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
-        runs = {"fwd": (cnt, lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st)),
+                dgrad_fn = lambda sh_: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh_, st)   # noqa: E731
+        runs = {"fwd": (cnt, lambda sh_: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh_, st)),
                 "dgrad": (n_dx, dgrad_fn),
-                "wgrad": (n_dw, lambda: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh, st))}
+                "wgrad": (n_dw, lambda sh_: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh_, st))}
         for kind, (calls, fn) in runs.items():
             if not calls or (x3 and keys[kind][0] < 3):   # bf16x3 pass: only its own rows (kinds 3, 4, 5)
                 continue
             Cb = keys[kind][3]
-            lib.gim_conv_tune_override(0, 0, 0)
-            t_auto = time_ms(fn)
+            t_auto = time_ms(lambda: fn(sh))
             best = (t_auto, 0, 0)
             if kind == "wgrad":
                 cands = [(0, 0, tg) for tg in (256, 512, 2048, 4096)]
@@ -126,11 +128,10 @@ def main():
                 tiles = [128, 641, 1264, 64] if Cb > 64 else ([1264, 64] if Cb > 32 else [])
                 cands = [(tl, ks, 0) for tl in tiles for ks in (1, 2, 3, 4, 6, 8)]
             for tl, ks, tg in cands:
-                lib.gim_conv_tune_override(tl, ks, tg)
-                t = time_ms(fn, reps=10)
+                shc = shape(tl if tl else -1, ks, tg)
+                t = time_ms(lambda: fn(shc), reps=10)
                 if t < best[0]:
                     best = (t, tl, ks if kind != "wgrad" else tg)
-            lib.gim_conv_tune_override(0, 0, 0)
             tot_auto += calls * t_auto
             tot_best += calls * best[0]
             gain = t_auto / best[0] - 1.0

@@ -36,7 +36,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     u = bench.UNIT[args.workload]
-    m, n, k, B = 1, 5, 10, args.batch
+    (m, n, k), B = u.get("mnk", (1, 5, 10)), args.batch
     G, tr = bench.build_trainer(u["S"], u["C"], n, m, k, dev)
     trainer = G.DataParallelMock(tr)
     leaked, real, si = bench.synthetic_batch(B, m, n, k, u["C"], u["S"], dev, 1234)
@@ -66,48 +66,48 @@ def main():
         N, H, W, Cin, Cout, KH, ups, slope, pool, fold = cfg
         n_dx = sum(c for (cf, dx, dw), c in bwd_calls.items() if cf == cfg and dx)
         n_dw = sum(c for (cf, dx, dw), c in bwd_calls.items() if cf == cfg and dw)
-        sh = _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0)
+        prec = ops.conv_precision()
+        sh = _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0, prec)
         x = torch.randn(N, H >> ups, W >> ups, Cin, device=dev)
         KF = KH + 1 if fold else KH
         w = torch.randn(Cout, KF, KF, Cin, device=dev) * 0.05   # folded layout when fold
-        wplain = torch.randn(Cout, KH, KH, Cin, device=dev) * 0.05
         y = torch.randn(N, H >> pool, W >> pool, Cout, device=dev)
         lowdx = 1 if (ups and fold) else 0
         dx = torch.empty(N, H >> lowdx, W >> lowdx, Cin, device=dev)
-        ns = lib.gim_conv2d_wgrad_slabs(sh)
-        slabs = torch.empty(ns * Cout * KF * KF * Cin, device=dev)
-        dw = torch.empty(Cout * KH * KH * Cin, device=dev)
-        scr = torch.empty(512 + Cout * KF * KF * Cin, device=dev)
-        foldmode = (2 if ups else 1) if fold else 0
-        flops = 2.0 * N * H * W * Cout * Cin * KH * KH
+        ns = 1   # pixel slices combined with float atomics, as in the training step
+        slabs = torch.zeros(ns * Cout * KF * KF * Cin, device=dev)
+        flops = ops.conv_executed_flops(N, H, W, Cin, Cout, KH, ups, pool, fold)      # what the kernels execute (folds!)
+        algo = ops.conv_algorithmic_flops(N, H, W, Cin, Cout, KH)                      # the unfused reference op
         t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
-        if lib.gim_conv_precision(-1) == 1 and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
+        if prec == 1 and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
             wt = torch.empty(Cin * KF * KF * Cout, device=dev)
             lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
             t_d = time_ms(lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
         else:
             t_d = time_ms(lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
 
-        def wg():
-            lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st)
-            lib.gim_wgrad_finish(slabs.data_ptr(), None, ns, None, None, None, None, dw.data_ptr(), None, scr.data_ptr(), Cout, Cin, KH, foldmode, None, None, st)
+        def wg():   # the step's form: accumulate into an arena slot (the finish of all convs is two batched launches per pass)
+            lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, sh, st)
         t_w = time_ms(wg) if n_dw else 0.0
         total = cnt * t_f + n_dx * t_d + n_dw * t_w
         tot["fwd"] += cnt * t_f
         tot["dgrad"] += n_dx * t_d
         tot["wgrad"] += n_dw * t_w
         tot["gflop"] += flops * (cnt + n_dx + n_dw) / 1e9
+        tot["algo"] += algo * (cnt + n_dx + n_dw) / 1e9
         rows.append((total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns))
     rows.sort(reverse=True)
     print("%-46s %4s %4s %4s %8s | %8s %6s | %8s %6s | %8s %6s %4s | %8s" %
-          ("N,H,W,Cin,Cout,K,ups,slope,pool,fold", "fwd", "dx", "dw", "GF", "fwd ms", "TF", "dgrad ms", "TF", "wgrad ms", "TF", "S", "tot ms"))
+          ("N,H,W,Cin,Cout,K,ups,slope,pool,fold", "fwd", "dx", "dw", "exe GF", "fwd ms", "TF", "dgrad ms", "TF", "wgrad ms", "TF", "S", "tot ms"))
+    print("(GF = FLOPs one launch EXECUTES: the pool / sub-pixel folds run (K+1)^2 taps at a quarter of the pixels; TF = executed TFLOP/s)")
     for total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns in rows:
         tf = lambda t: flops / t / 1e9 if t else 0.0  # noqa: E731
         print("%-46s %4d %4d %4d %8.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f %4d | %8.2f" %
               (",".join(str(c) for c in cfg), cnt, n_dx, n_dw, flops / 1e9, t_f, tf(t_f), t_d, tf(t_d), t_w, tf(t_w), ns, total))
     s = tot["fwd"] + tot["dgrad"] + tot["wgrad"]
-    print("sum of conv/linear kernels per step: %.1f ms (fwd %.1f, dgrad %.1f, wgrad %.1f); executed %.0f GFLOP -> %.1f TFLOP/s"
-          % (s, tot["fwd"], tot["dgrad"], tot["wgrad"], tot["gflop"], tot["gflop"] / s))
+    print("sum of conv/linear kernels per step: %.1f ms (fwd %.1f, dgrad %.1f, wgrad %.1f); executed %.0f GFLOP -> %.1f TFLOP/s = %.3f of the "
+          "fp32 MFMA peak (algorithmic, unfused ops at full resolution: %.0f GFLOP -> %.1f TFLOP/s)"
+          % (s, tot["fwd"], tot["dgrad"], tot["wgrad"], tot["gflop"], tot["gflop"] / s, tot["gflop"] / s / 157.3, tot["algo"], tot["algo"] / s))
 
 
 if __name__ == "__main__":

@@ -1,7 +1,11 @@
 """Launch ONE convolution shape repeatedly through the C ABI (for rocprofv3 --pmc / --kernel-trace runs).
 
-    python tools/kernel_probe.py fwd|dgrad|wgrad N H Cin Cout K [ups] [reps]
+    python tools/kernel_probe.py fwd|dgrad|wgrad N H Cin Cout K [ups] [reps] [pool] [prec] [tile] [ksplit|wgrad target]
+
+pool = 1 (or ups = 1 with K > 1): the folded form the engine launches for that layer.  prec 1 = bf16x3.  tile / ksplit:
+launch overrides (gim_conv_shape.tune_*; 0 = table / heuristic, tile < 0 = heuristic only).
 """
+import ctypes
 import os
 import sys
 
@@ -9,32 +13,38 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from optimalstrategiesagainstgenerativeattacks_amd import _lib  # noqa: E402
+from optimalstrategiesagainstgenerativeattacks_amd import _lib, ops  # noqa: E402
 
 
 def main():
     kind = sys.argv[1]
     N, H, Cin, Cout, K = [int(a) for a in sys.argv[2:7]]
-    ups = int(sys.argv[7]) if len(sys.argv) > 7 else 0
-    reps = int(sys.argv[8]) if len(sys.argv) > 8 else 5
+    arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d   # noqa: E731
+    ups, reps, pool, prec, tile, ks = arg(7, 0), arg(8, 5), arg(9, 0), arg(10, 0), arg(11, 0), arg(12, 0)
+    fold = 1 if (pool or (ups and K > 1)) else 0
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, 0.2)
+    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, 0.2, pool, fold, 0, prec, tile, 0 if kind == "wgrad" else ks, ks if kind == "wgrad" else 0)
+    KF = K + 1 if fold else K
     x = torch.randn(N, H >> ups, H >> ups, Cin, device=dev)
-    w = torch.randn(Cout, K, K, Cin, device=dev) * 0.05
-    y = torch.randn(N, H, H, Cout, device=dev)
-    dx = torch.empty(N, H, H, Cin, device=dev)
-    ns = lib.gim_conv2d_wgrad_slabs(sh)
-    slabs = torch.empty(ns * Cout * K * K * Cin, device=dev)
+    w = torch.randn(Cout, KF, KF, Cin, device=dev) * 0.05
+    y = torch.randn(N, H >> pool, H >> pool, Cout, device=dev)
+    lo = 1 if (ups and fold) else 0
+    dx = torch.empty(N, H >> lo, H >> lo, Cin, device=dev)
+    acc = torch.zeros(Cout * KF * KF * Cin, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     dgrad = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
-    if lib.gim_conv_precision(-1) == 1 and Cout % 16 == 0 and Cin >= 32 and not ups:   # bf16x3 path: dgrad on transposed weights (ops._conv_dgrad)
-        wt = torch.empty(Cin * K * K * Cout, device=dev)
-        lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, K, st)
+    plan_kind = {"fwd": 0, "dgrad": 1, "wgrad": 3}[kind]
+    if prec == 1 and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold):   # bf16x3 path: dgrad on transposed weights (ops._conv_dgrad)
+        wt = torch.empty(Cin * KF * KF * Cout, device=dev)
+        lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
         dgrad = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
+        plan_kind = 2 if kind == "dgrad" else plan_kind
     fn = {"fwd": lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st),
           "dgrad": dgrad,
-          "wgrad": lambda: lib.gim_conv2d_wgrad(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, ns, sh, st)}[kind]
+          "wgrad": lambda: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh, st)}[kind]
+    plan = (ctypes.c_int32 * 8)()
+    lib.gim_conv_launch_plan(sh, plan_kind, ctypes.cast(plan, ctypes.c_void_p))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn()
     torch.cuda.synchronize()
@@ -44,8 +54,9 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * N * H * H * Cout * Cin * K * K
-    print("%s N=%d H=%d Cin=%d Cout=%d K=%d ups=%d: %.3f ms  %.1f TFLOP/s" % (kind, N, H, Cin, Cout, K, ups, ms, flops / ms / 1e9))
+    flops = ops.conv_executed_flops(N, H, H, Cin, Cout, K, ups, pool, fold)
+    print("%s N=%d H=%d Cin=%d Cout=%d K=%d ups=%d pool=%d prec=%d plan[table,BM,BN,split,gx,gy,gz,path]=%s: %.3f ms  %.1f executed TFLOP/s"
+          % (kind, N, H, Cin, Cout, K, ups, pool, prec, list(plan), ms, flops / ms / 1e9))
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import optimalstrategiesagainstgenerativeattacks_amd as G  # noqa: E402
-from optimalstrategiesagainstgenerativeattacks_amd import _lib  # noqa: E402
+from optimalstrategiesagainstgenerativeattacks_amd import ops  # noqa: E402
 from oracle import gim_oracle as go  # noqa: E402
 from tests.helpers import episode, filled_sd, load_keys, relerr  # noqa: E402
 from tests.test_gpu_models import _product_models  # noqa: E402
@@ -20,7 +20,6 @@ dev = torch.device("cuda:0")
 tag, cfg = "curve", "16_1_32"
 B, m, n, k, c, s, d = 4, 1, 3, 4, 1, 16, 32
 keys = load_keys(cfg)
-lib = _lib.load()
 
 
 def f32(sd):
@@ -42,8 +41,8 @@ for it in range(iters):
     g32, d32 = o32.step(leaked.float(), real.float(), si.float(), z.float())
     row = [(relerr(g32[0].mean().double(), g64[0].mean()), relerr(d32[0].mean().double(), d64[0].mean()))]
     for name, (mode, trainer) in prods.items():
-        lib.gim_conv_precision(mode)
+        ops.set_conv_precision(mode)
         gi, di = G.gim_step(trainer, *[t.float().to(dev) for t in (leaked, real, si)], z=z.float().to(dev))
         row.append((relerr(gi[0], g64[0].mean()), relerr(di[0], d64[0].mean())))
-    lib.gim_conv_precision(0)
+    ops.set_conv_precision(0)
     print("%3d | %s" % (it, " | ".join("G %.2e  D %.2e" % r for r in row)), flush=True)
