@@ -339,9 +339,283 @@ def gen_gaussian():
     print("gaussian: done")
 
 
+def gen_subnets():
+    """the three sub-networks of the generator / authenticator ON THEIR OWN (tiny config 16x16x1, style 32,
+    conditioned fill), so that a failure localises below "G step": outputs, input gradients, every parameter gradient and the
+    spectral-norm buffers after the call.  models/gim_img_models.py:19-57 (Encoder), :63-95 (EnvDecoder), :218-257 (AdaInImage2Image)."""
+    st = {}
+    run_block(st, "encoder", gim.Encoder(16, 1, 32), {"x": (3, 1, 16, 16)}, lambda m, x: m(x))
+    run_block(st, "envdecoder", gim.EnvDecoder(16, 1, 32), {"x": (3, 32)}, lambda m, x: m(x))
+    run_block(st, "img2img", gim.AdaInImage2Image(img_size=16, in_channels=2, out_channels=1, style_dim=32),
+              {"x": (3, 2, 16, 16), "style": (3, 32)}, lambda m, x, style: m(x=x, style=style))
+    np.savez_compressed(os.path.join(OUT, "subnets.npz"), **st)
+    print("subnets.npz:", len(st), "arrays")
+
+
+# full gradient tensors at the benchmark shapes would be tens of MB per fixture; a fixed strided subsample of the flattened
+# [Cout, Cin, kh, kw] gradient pins the position of every kept element (a per-tensor norm is blind to tap / channel order).
+# (the numbers in the table are only a note of each tensor's role; the stride is chosen from the tensor's size, see sample())
+BENCH_GRAD_SAMPLES = {
+    "im": {"img2img.down_block.down_blocks.0.conv_r2.weight_orig": 7,          # the 9x9 64 -> 64 (32x32x1: 9x9 64 -> 64 too)
+           "img2img.adain_res_block.res_blocks.2.conv1.weight_orig": 61,       # a 512 -> 512 3x3
+           "img2img.adain_up_block.up_blocks.0.conv_l1.weight_orig": 3,        # a 1x1 skip conv
+           "env_decoder.up_blocks.2.conv_r1.weight_orig": 31,                  # sub-pixel (upsampled) 3x3
+           "img2img.adain_res_block.res_blocks.0.lin1_std.weight": 5},         # a style linear
+    "au": {"src_encoder.down_blocks.%(last)d.conv_r2.weight_orig": 61,         # the 512 -> 512 3x3 (pool-folded)
+           "env_encoder.down_blocks.1.conv_l1.weight_orig": 1,                 # a 1x1 skip conv (full)
+           "src_encoder.down_blocks.0.conv_r1.weight_orig": 1,                 # the image layer (3 / 1 input channels, full)
+           "src_encoder.att.conv_h.weight_orig": 3,
+           "dis.stat.fc.stat.model.2.weight": 37},
+}
+
+
+def gen_bench_grads(tag, s, c, d, B, m, n, k, dtype):
+    """Same weights, inputs and protocol as gen_nets(tag, ...): strided samples of selected gradient TENSORS of the G step and
+    of the D step at a benchmark shape (the fixture nets_<tag>.npz pins losses / logits / per-tensor gradient norms)."""
+    torch.set_default_dtype(dtype)
+    st = {}
+    au, im = make_models(s, c, d, tag + "/", dtype)
+    leaked, real, si, z = episode(tag, B, m, n, k, c, s, d, dtype)
+    with tempfile.TemporaryDirectory() as td:
+        tr = GIMImgTrainer(td, m, n, k, au, im, 1e-4, 1e-4, 1e-6, reg_param=0.0)
+    au.train(); im.train()
+    with inject_randn(z):
+        loss, fake, out = tr.forward(mode="impersonator_forward", leaked_sample=leaked, si_sample=si)
+    loss.mean().backward()
+    last = len(au.src_encoder.down_blocks) - 1
+    gi = grads_of(im)
+
+    def sample(prefix, name, arr):   # at most ~20 000 values per tensor, prime stride, float32 (compared at 1e-3)
+        stride = next(p_ for p_ in (1, 3, 7, 13, 31, 61, 127, 251, 509, 1021, 2039) if p_ * 20000 >= arr.size)
+        st["%s/%d/%s" % (prefix, stride, name)] = arr.reshape(-1)[::stride].astype(np.float32)
+    for name in BENCH_GRAD_SAMPLES["im"]:
+        sample("g", name, gi[name])
+    au.zero_grad(); im.zero_grad()
+    res = tr.forward(mode="authenticator_forward", fake_sample=fake.detach(), real_sample=real, si_sample=si)
+    res[0].mean().backward()
+    ga = grads_of(au)
+    for name in BENCH_GRAD_SAMPLES["au"]:
+        name = name % {"last": last}
+        sample("d", name, ga[name])
+    np.savez_compressed(os.path.join(OUT, "nets_%s_grads.npz" % tag), **st)
+    torch.set_default_dtype(torch.float32)
+    print("nets_%s_grads: %d arrays, %d values" % (tag, len(st), sum(v.size for v in st.values())))
+
+
+def gen_ckpt():
+    """A checkpoint WRITTEN BY THE REFERENCE (training/checkpoints.py:21-44 through GIMImgTrainer.save, training/gim_img_trainer.py:
+    163-172): model + torch.optim.Adam state + GlobalStep after 3 iterations of the reference's own loop on a small config
+    (16x16x1, style 16, fp32 - the reference's native dtype; ~0.8 MB), and what the reference's 4th iteration then returns.
+    The product must load the file with resume_from_ckpt and reproduce that 4th iteration."""
+    import shutil
+    s, c, d, B, m, n, k = 16, 1, 16, 3, 1, 3, 4
+    tag = "ckpt"
+    torch.set_default_dtype(torch.float32)
+    au, im = make_models(s, c, d, tag + "/", torch.float32)
+    st = {}
+    with tempfile.TemporaryDirectory() as td:
+        tr = GIMImgTrainer(td, m, n, k, au, im, au_lr=2e-3, im_lr=1e-3, env_noise_mapping_lr=1e-4, reg_param=0.0)
+        trainer = DataParallelMock(tr)
+        for it in range(4):
+            leaked, real, si, z = episode("%s/it%d" % (tag, it), B, m, n, k, c, s, d, torch.float32)
+            tr.do_global_step()
+            tr.update_learning_rate()
+            with inject_randn(z):
+                g = git_.im_train_step(trainer, leaked, si)
+            dres = git_.au_train_step(trainer, real, g[1], si)
+            if it == 2:
+                tr.save(epoch=0)
+                src = os.path.join(td, "ckpts", "model_%08d.pt" % tr.global_step)
+                assert tr.global_step == 2 and os.path.exists(src)
+                shutil.copy(src, os.path.join(OUT, "ref_ckpt_model_00000002.pt"))
+            if it == 3:
+                st["g_loss"], st["g_out"], st["fake"] = g[0].numpy(), g[2].numpy(), g[1].numpy()
+                for i, nm in enumerate(["loss", "loss_real", "loss_fake", "reg", "out_real", "out_fake"]):
+                    st["d_" + nm] = np.asarray(dres[i].numpy())
+    np.savez_compressed(os.path.join(OUT, "ref_ckpt_step4.npz"), **st)
+    with open(os.path.join(OUT, "ref_ckpt.json"), "w") as f:
+        json.dump({"config": dict(s=s, c=c, d=d, B=B, m=m, n=n, k=k, au_lr=2e-3, im_lr=1e-3, noise_lr=1e-4, tag=tag),
+                   "au_keys": key_list(au), "im_keys": key_list(im),
+                   "size_bytes": os.path.getsize(os.path.join(OUT, "ref_ckpt_model_00000002.pt"))}, f)
+    print("ref_ckpt: done")
+
+
+class _Recorder:
+    """Stands in for training/logger.py:12-92 (tensorboardX / torchvision are absent): records what the loop logs."""
+
+    def __init__(self):
+        self.scalars, self.imgs = [], []
+
+    def add_scalar(self, category, k, v, global_step):
+        self.scalars.append([category, k, int(global_step), float(v)])
+
+    def add_imgs(self, imgs, category, k, global_step, nrow=5):
+        self.imgs.append([category, k, int(global_step), list(imgs.shape), float(imgs.double().sum()), float(imgs.double().abs().max())])
+
+
+class _MemDS(torch.utils.data.Dataset):
+    """In-memory episodes with the sample contract of ImgGIMDataSet.__getitem__ (data_handling/img_datasets.py:68-103)."""
+
+    def __init__(self, tag, n_ex, m, n, k, c, s, dtype):
+        def img(name, i, t):
+            return T(np.clip(pf.normal("%s/%d/%s" % (tag, i, name), (t, c, s, s)) * 0.5, -1, 1), dtype)
+        self.ex = [{"real_sample": img("real", i, n), "leaked_sample": img("leaked", i, m), "si_sample": img("si", i, k),
+                    "class": i, "class_name": "c%d" % i} for i in range(n_ex)]
+
+    def __len__(self):
+        return len(self.ex)
+
+    def __getitem__(self, i):
+        return self.ex[i]
+
+
+class inject_randn_seq:
+    """Every torch.randn call inside returns the portable normal keyed by the call's index and shape (latent noise z is drawn
+    inside GIMFaceImpersonator.forward, models/gim_img_models.py:374, also by the image dumps of the loop)."""
+
+    def __init__(self, tag, dtype):
+        self.tag, self.dtype, self.n = tag, dtype, 0
+
+    def __enter__(self):
+        self._orig = torch.randn
+        outer = self
+
+        def fake(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            z = T(pf.normal("%s/z%d" % (outer.tag, outer.n), shape), outer.dtype)
+            outer.n += 1
+            return z
+        torch.randn = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.randn = self._orig
+
+
+def gen_loop():
+    """The reference's caller loop itself (training/gim_img_training.py:186-354 train_epoch, :98-154 eval_step, :23-73 image dumps)
+    for two epochs of two iterations on a fixed in-memory dataset, every cadence set so that it fires: the stream of logged
+    scalars, the image-dump events and the checkpoint calls.  fp64, tiny config, n_au_steps = 2 (eval-mode generator passes)."""
+    s, c, d, m, n, k = 16, 1, 32, 1, 3, 4
+    tag = "loop"
+    torch.set_default_dtype(torch.float64)
+    au, im = make_models(s, c, d, tag + "/", torch.float64)
+    train_ds = _MemDS(tag + "/train", 7, m, n, k, c, s, torch.float64)
+    val_ds = _MemDS(tag + "/val", 4, m, n, k, c, s, torch.float64)
+    rec = _Recorder()
+    saves = []
+    cfg = dict(train_batch_size=3, val_batch_size=2, save_every=3, eval_every=2, save_imgs_every=2, train_eval_indices=[0, 5],
+               val_eval_indices=[1], tb_log_every=1, tb_log_enc_every=2, n_au_steps=2, n_epochs=2, seed=123,
+               au_lr=2e-3, im_lr=1e-3, noise_lr=1e-4, milestones=[2], gamma=0.5)
+    with tempfile.TemporaryDirectory() as td:
+        tr = GIMImgTrainer(td, m, n, k, au, im, au_lr=cfg["au_lr"], im_lr=cfg["im_lr"], env_noise_mapping_lr=cfg["noise_lr"],
+                           lr_milestones=tuple(cfg["milestones"]), lr_gamma=cfg["gamma"], reg_param=0.0)
+        orig_save = tr.save
+        tr.save = lambda epoch: (saves.append([int(tr.global_step), int(epoch)]), orig_save(epoch=epoch))[1]
+        trainer = DataParallelMock(tr)
+        torch.manual_seed(cfg["seed"])     # the DataLoader's shuffle draws its seed from the default generator
+        with inject_randn_seq(tag, torch.float64) as inj:
+            for ep in range(cfg["n_epochs"]):
+                git_.train_epoch(device="cpu", logger=rec, epoch=ep, trainer=trainer, train_ds=train_ds, val_ds=val_ds,
+                                 train_batch_size=cfg["train_batch_size"], val_batch_size=cfg["val_batch_size"], num_workers=0,
+                                 save_every=cfg["save_every"], eval_every=cfg["eval_every"], save_imgs_every=cfg["save_imgs_every"],
+                                 train_eval_indices=cfg["train_eval_indices"], val_eval_indices=cfg["val_eval_indices"],
+                                 tb_log_every=cfg["tb_log_every"], tb_log_enc_every=cfg["tb_log_enc_every"], n_au_steps=cfg["n_au_steps"])
+            n_z = inj.n
+        ckpts = sorted(os.listdir(os.path.join(td, "ckpts")))
+    with open(os.path.join(OUT, "loop.json"), "w") as f:
+        json.dump({"config": dict(cfg, s=s, c=c, d=d, m=m, n=n, k=k, n_train=7, n_val=4), "scalars": rec.scalars, "imgs": rec.imgs,
+                   "saves": saves, "ckpt_files": ckpts, "n_randn_calls": n_z, "final_global_step": int(tr.global_step),
+                   "au_final": tensor_stats(au.state_dict()), "im_final": tensor_stats(im.state_dict())}, f)
+    torch.set_default_dtype(torch.float32)
+    print("loop.json: %d scalars, %d image dumps, saves %s, %d randn calls" % (len(rec.scalars), len(rec.imgs), saves, n_z))
+
+
+def gen_data():
+    """The dataset sample contract (data_handling/img_datasets.py:24-110 ImgGIMDataSet, :270-303 load_image / process_pil_image /
+    adjust_dynamic_range): the reference's dataset class reads PNG files written here from portable-fill uint8 images and returns
+    its example dicts; the fixture holds the uint8 bank, and per example the source image index and flip flag of every returned
+    image (recovered by exact match) next to the returned float tensors.
+    torchvision==0.4.0 (requirements.txt:14) is absent from the image: the three transforms the path touches are supplied per
+    their published behaviour - ToTensor (uint8 HWC -> float32 CHW / 255), RandomHorizontalFlip (python random() < 0.5 ->
+    PIL FLIP_LEFT_RIGHT), Compose - everything else executed is the reference's own code."""
+    import random
+    from PIL import Image
+    tvt = sys.modules["torchvision.transforms"]
+
+    class ToTensor:
+        def __call__(self, pic):
+            a = np.array(pic, dtype=np.uint8)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            return torch.from_numpy(a.transpose(2, 0, 1).copy()).float().div(255)
+
+    class RandomHorizontalFlip:
+        def __init__(self, p=0.5):
+            self.p = p
+
+        def __call__(self, img):
+            return img.transpose(Image.FLIP_LEFT_RIGHT) if random.random() < self.p else img
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, img):
+            for t in self.ts:
+                img = t(img)
+            return img
+    tvt.ToTensor, tvt.RandomHorizontalFlip, tvt.Compose = ToTensor, RandomHorizontalFlip, Compose
+    import data_handling.img_datasets as ids
+    S, C, m, n, k = 8, 3, 1, 3, 4
+    sizes = [9, 8, 11, 5]            # the last class has fewer than m + n + k images: filtered out (img_datasets.py:59-61)
+    bank, offs = [], [0]
+    with tempfile.TemporaryDirectory() as root:
+        for ci, sz in enumerate(sizes):
+            os.makedirs(os.path.join(root, "train", "cls%02d" % ci))
+            for j in range(sz):
+                a = (pf.uniform("data/%d/%d" % (ci, j), (S, S, C), 0.0, 256.0)).astype(np.uint8)
+                Image.fromarray(a, "RGB").save(os.path.join(root, "train", "cls%02d" % ci, "img%03d.png" % j))
+                bank.append(a)
+            offs.append(offs[-1] + sz)
+        bank = np.stack(bank)
+        ds = ids.ImgGIMDataSet(root=root, split="train", img_channels=C, img_size=S, m=m, n=n, si=k, example_cnt_per_class=2,
+                               img_suffix=".png", mirror=True)
+        st = {"bank": bank, "offsets": np.asarray(offs), "len": np.asarray(len(ds)), "n_classes": np.asarray(ds.n_classes)}
+        names = sorted(os.listdir(os.path.join(root, "train")))
+        random.seed(11)
+        meta = []
+        for e, index in enumerate([0, 3, 5, 2]):
+            ex = ds[index]
+            cls_dir = ex["class_name"]
+            ci = names.index(cls_dir)
+            meta.append({"index": index, "class": int(ex["class"]), "class_name": cls_dir, "bank_class": ci})
+            for part in ("leaked_sample", "real_sample", "si_sample"):
+                t = ex[part]
+                st["ex%d/%s" % (e, part)] = t.numpy()
+                src, flips = [], []
+                for img in t:     # which bank image, flipped or not: exact match in uint8 space
+                    u8 = np.rint((img.numpy().transpose(1, 2, 0) + 1.0) * 127.5).astype(np.uint8)
+                    hit = [(j, f) for j in range(offs[ci], offs[ci + 1]) for f in (0, 1)
+                           if np.array_equal(bank[j][:, ::-1] if f else bank[j], u8)]
+                    assert len(hit) == 1, hit
+                    src.append(hit[0][0]); flips.append(hit[0][1])
+                st["ex%d/%s/src" % (e, part)] = np.asarray(src, dtype=np.int32)
+                st["ex%d/%s/flip" % (e, part)] = np.asarray(flips, dtype=np.uint8)
+        # process_pil_image with a real resize (12x12 -> 8x8 bilinear) and adjust_dynamic_range on its own
+        big = (pf.uniform("data/big", (12, 12, C), 0.0, 256.0)).astype(np.uint8)
+        st["resize/in"] = big
+        st["resize/out"] = ids.process_pil_image(Image.fromarray(big, "RGB"), img_size=S).numpy()
+        st["adr/out"] = ids.adjust_dynamic_range(torch.from_numpy(bank[:2].astype(np.float32) / np.float32(255.0)), (0., 1.), (-1, 1)).numpy()
+    np.savez_compressed(os.path.join(OUT, "data.npz"), **st)
+    with open(os.path.join(OUT, "data.json"), "w") as f:
+        json.dump({"config": dict(S=S, C=C, m=m, n=n, k=k, sizes=sizes, example_cnt_per_class=2, python_random_seed=11), "examples": meta}, f)
+    print("data.npz: %d arrays" % len(st))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "keys", "tiny", "trainer", "bench", "gaussian"]
+    which = sys.argv[1:] or ["blocks", "keys", "tiny", "trainer", "bench", "gaussian", "subnets", "benchgrads", "ckpt", "loop", "data"]
     if "gaussian" in which:
         gen_gaussian()
     if "blocks" in which:
@@ -363,6 +637,19 @@ def main():
         gen_nets("vox64_f32", 64, 3, 512, 1, 1, 5, 10, torch.float32, full=False)
     if "bench128" in which:   # BASELINE config 5 shape (m > 1 leaked images), fp64
         gen_nets("vox128_f64", 128, 3, 512, 1, 2, 2, 3, torch.float64, full=False)
+    if "cfg5" in which:       # BASELINE config 5 AS STATED: 128x128x3, m=5 n=20 k=20 (one episode; ~13 TFLOP in fp64 on the CPU)
+        gen_nets("vox128_m5n20k20", 128, 3, 512, 1, 5, 20, 20, torch.float64, full=False)
+    if "subnets" in which:
+        gen_subnets()
+    if "benchgrads" in which:
+        gen_bench_grads("vox64_f64", 64, 3, 512, 1, 1, 5, 10, torch.float64)
+        gen_bench_grads("om32_f64", 32, 1, 512, 2, 1, 5, 10, torch.float64)
+    if "ckpt" in which:
+        gen_ckpt()
+    if "loop" in which:
+        gen_loop()
+    if "data" in which:
+        gen_data()
 
 
 if __name__ == "__main__":

@@ -77,6 +77,50 @@ def test_block_vs_reference_golden(name):
             assert relerr(bufs[k[len(name) + 3:]], g[k]) < 1e-5, k
 
 
+def _subnets():
+    from optimalstrategiesagainstgenerativeattacks_amd import gim_img_models as gm
+    return {
+        "encoder": (lambda: gm.Encoder(16, 1, 32), dict(x=(3, 1, 16, 16)), ("x",)),
+        "envdecoder": (lambda: gm.EnvDecoder(16, 1, 32), dict(x=(3, 32)), ("x",)),
+        "img2img": (lambda: gm.AdaInImage2Image(img_size=16, in_channels=2, out_channels=1, style_dim=32),
+                    dict(x=(3, 2, 16, 16), style=(3, 32)), ("x", "style")),
+    }
+
+
+@pytest.mark.parametrize("name", ["encoder", "envdecoder", "img2img"])
+def test_subnet_vs_reference_golden(name):
+    """Encoder / EnvDecoder / AdaInImage2Image on their own (models/gim_img_models.py:19-57, 63-95, 218-257)
+    against the reference's fp64 run on the same named weights and inputs: output, input gradients, EVERY parameter gradient,
+    spectral-norm buffers after the call."""
+    g = load_npz("subnets.npz")
+    ctor, inputs, order = _subnets()[name]
+    mod = fill_module(ctor(), name + "/").train()
+    xs = {}
+    for k, s in inputs.items():
+        a = T(pf.normal("%s/%s" % (name, k), s))
+        xs[k] = (nhwc(a) if a.dim() == 4 else a.float().to(dev())).requires_grad_()
+    y = mod(*[xs[k] for k in order])
+    yc = nchw(y) if y.dim() == 4 else y
+    ref = g[name + "/y"]
+    assert relerr(yc, ref) < 1e-4, "output"
+    r = T(pf.uniform(name + "/r", tuple(ref.shape)))
+    (y * (nhwc(r) if r.dim() == 4 else r.float().to(dev()))).sum().backward()
+    for k in inputs:
+        gx = xs[k].grad
+        assert relerr(nchw(gx) if gx.dim() == 4 else gx, g["%s/d_%s" % (name, k)], atol=1e-6) < 1e-3, "d_" + k
+    params = dict(mod.named_parameters())
+    bufs = dict(mod.named_buffers())
+    gmax = max(float(np.linalg.norm(g[k])) for k in g.files if k.startswith(name + "/g/"))
+    n_g = 0
+    for k in g.files:
+        if k.startswith(name + "/g/"):
+            assert relerr_floor(params[k[len(name) + 3:]].grad, g[k], 1e-3 * gmax) < 1e-3, k
+            n_g += 1
+        if k.startswith(name + "/b/"):
+            assert relerr(bufs[k[len(name) + 3:]], g[k]) < 1e-5, k
+    assert n_g == len(params)
+
+
 def _product_models(tag, cfg, use_img_att=False):
     import optimalstrategiesagainstgenerativeattacks_amd as G
     s, c, d = map(int, cfg.split("_"))
@@ -98,10 +142,27 @@ def _grad_norm_check(mod, ref, tol, floor_frac, what):
     assert not bad, "%s: %d/%d grad norms off, first: %s" % (what, len(bad), len(ref), bad[:5])
 
 
+def _check_grad_samples(mod, gs, prefix, tol, what):
+    """nets_<tag>_grads.npz: strided samples g.reshape(-1)[::stride] of whole gradient TENSORS (logical [Cout, Cin, kh, kw]
+    order) from the reference - position-sensitive, unlike the per-tensor norms."""
+    params = dict(mod.named_parameters())
+    n = 0
+    for k in gs.files:
+        if not k.startswith(prefix):
+            continue
+        _, stride, name = k.split("/", 2)
+        got = params[name].grad.detach().double().cpu().reshape(-1)[::int(stride)]
+        e = relerr(got, gs[k])
+        assert e < tol, (what, name, "gradient tensor sample", e)
+        n += 1
+    assert n >= 5, (what, n)
+
+
 def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3, use_img_att=False):
     import optimalstrategiesagainstgenerativeattacks_amd as G
     import tempfile
     g = load_npz("nets_%s.npz" % tag)
+    gs = load_npz("nets_%s_grads.npz" % tag) if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "nets_%s_grads.npz" % tag)) else None
     meta = load_json("nets_%s.json" % tag)
     c = meta["config"]
     au, im = _product_models(tag, cfg, use_img_att)
@@ -117,6 +178,8 @@ def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3, use_img_att=False):
     assert relerr(fake[:gf.shape[0], :gf.shape[1]], gf) < tol, "fake images"
     loss.mean().backward()
     _grad_norm_check(im, meta["meta"]["g/im_grad_norms"], gtol, floor_frac, "G step")
+    if gs is not None:
+        _check_grad_samples(im, gs, "g/", 1e-3, "G step")
     for k in g.files:
         if k.startswith("g/grad/"):
             assert relerr(dict(im.named_parameters())[k[7:]].grad, g[k], atol=1e-7) < gtol, k
@@ -127,6 +190,8 @@ def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3, use_img_att=False):
     assert (res[6].cpu().numpy() == g["d/pred_real"]).all() and (res[7].cpu().numpy() == g["d/pred_fake"]).all()
     res[0].mean().backward()
     _grad_norm_check(au, meta["meta"]["d/au_grad_norms"], gtol, floor_frac, "D step")
+    if gs is not None:
+        _check_grad_samples(au, gs, "d/", 1e-3, "D step")
     for k in g.files:
         if k.startswith("d/grad/"):
             assert relerr(dict(au.named_parameters())[k[7:]].grad, g[k], atol=1e-7) < gtol, k
@@ -192,6 +257,13 @@ def _assert_final_state(mod, ref, walk, what):
     assert not bad, "%s: %d/%d tensors off the reference's final state, first: %s" % (what, len(bad), len(ref), bad[:4])
 
 
+def test_config5_as_stated_m5_n20_k20_vs_reference_golden():
+    """BASELINE config 5 at its stated set sizes: 128x128x3, m = 5 leaked, n = 20 generated, k = 20 registration images, one
+    episode (models/gim_img_models.py:364-423 with m > 1, models/gim_basic_models.py:152-172 with 20-image sets), reference run
+    in fp64.  The engine computes in fp32 storage (fp32 MFMA, or bf16x3 at fp32 accuracy): DESIGN.md section 8."""
+    _check_nets("vox128_m5n20k20", "128_3_512", 1e-3, 5e-2)
+
+
 @pytest.mark.parametrize("tag", ["reg0", "reg10", "nau2"])
 def test_trainer_protocol_vs_reference_golden(tag):
     """Real step protocol (im_train_step / im_eval_step + au_train_step, MultiStepLR, FusedAdam) for consecutive
@@ -237,15 +309,16 @@ def test_trainer_protocol_vs_reference_golden(tag):
             assert relerr(dres[i], ref) < tol or float(np.abs(ref).max()) == 0.0, (it, nm)
         assert (dres[6].cpu().numpy() == g["it%d/d_pred_real" % it]).all() and (dres[7].cpu().numpy() == g["it%d/d_pred_fake" % it]).all()
     # eval-mode pass afterwards: no power iteration, no gradients (im_eval_step / au_eval_step)
-    state_before = {k_: v.clone() for k_, v in list(au.state_dict().items()) + list(im.state_dict().items())}
+    state_before = {(nm, k_): v.clone() for nm, mod in (("au", au), ("im", im)) for k_, v in mod.state_dict().items()}
     leaked, real, si, z = [t.float().to(dev()) for t in episode(tag + "/eval", c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
     ge = G.im_eval_step(trainer, leaked, si, z=z)
     de = G.au_eval_step(trainer, real, ge[1], si)
     assert relerr(ge[0], g["eval/g_loss"]) < 1e-4 and relerr(ge[2], g["eval/g_out"]) < 1e-4
     assert relerr(de[0], g["eval/d_loss"]) < 1e-4
     assert relerr(de[4], g["eval/d_out_real"]) < 1e-4 and relerr(de[5], g["eval/d_out_fake"]) < 1e-4
-    for k_, v in list(au.state_dict().items()) + list(im.state_dict().items()):
-        assert torch.equal(v, state_before[k_]), ("the eval pass changed state", k_)
+    for nm, mod in (("au", au), ("im", im)):
+        for k_, v in mod.state_dict().items():
+            assert torch.equal(v, state_before[(nm, k_)]), ("the eval pass changed state", nm, k_)
     # the state the protocol leaves behind
     m_ = meta["meta"]
     au_walk = _noise_walk(tr.authenticator_opt, au.named_parameters(), n_steps, c["au_lr"])
@@ -669,3 +742,177 @@ def test_authentication_eval_agents_on_episode_bank():
     b = next(iter(ds2.gpu_batches(4, False)))
     fake = rep.act(leaked_sample=b["leaked_sample"], n=n)
     assert fake.shape == b["real_sample"].shape and torch.equal(fake[:, 0], b["leaked_sample"][:, 0])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SURVEY.md 8(f).2 / 8(f).3 against fixtures the REFERENCE produced: a checkpoint file it wrote, the scalar stream of its own
+# train_epoch, the example dicts of its own dataset class (oracle/make_golden.py gen_ckpt / gen_loop / gen_data)
+# ------------------------------------------------------------------------------------------------------------------
+def test_resume_from_reference_written_checkpoint():
+    """tests/golden/ref_ckpt_model_00000002.pt was written by the reference's GIMImgTrainer.save after 3 iterations of its own
+    loop (training/checkpoints.py:21-44, training/gim_img_trainer.py:158-172: both state dicts, both torch.optim.Adam states,
+    GlobalStep).  resume_from_ckpt loads it - weights into channels-last storage, Adam moments into the flat buffers, the global
+    step - and the next iteration reproduces the reference's 4th."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    import tempfile
+    meta = load_json("ref_ckpt.json")
+    c = meta["config"]
+    g = load_npz("ref_ckpt_step4.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_ckpt_model_00000002.pt")
+    au, im = G.get_au(c["s"], c["c"], c["d"]), G.get_im(c["s"], c["c"], c["d"])
+    assert [[k_, list(v.shape)] for k_, v in au.state_dict().items()] == meta["au_keys"]
+    assert [[k_, list(v.shape)] for k_, v in im.state_dict().items()] == meta["im_keys"]
+    au, im = au.to(dev()), im.to(dev())
+    with tempfile.TemporaryDirectory() as td:
+        tr = G.GIMImgTrainer(td, c["m"], c["n"], c["k"], au, im, au_lr=c["au_lr"], im_lr=c["im_lr"],
+                             env_noise_mapping_lr=c["noise_lr"], reg_param=0.0)
+        tr.resume_from_ckpt(path)
+    assert tr.global_step == 2
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    for k_, v in ck["authenticator"].items():
+        assert torch.equal(au.state_dict()[k_].cpu(), v), k_
+    for k_, v in ck["impersonator"].items():
+        assert torch.equal(im.state_dict()[k_].cpu(), v), k_
+    trainer = G.DataParallelMock(tr)
+    leaked, real, si, z = [t.float().to(dev()) for t in
+                           episode("%s/it3" % c["tag"], c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
+    tr.do_global_step()
+    tr.update_learning_rate()
+    assert tr.global_step == 3
+    gres = G.im_train_step(trainer, leaked, si, z=z)
+    # the Adam moments the reference saved are the ones the update just used: after the first zero_grad / step the flat buffers
+    # hold beta2 * v_saved + (1 - beta2) g^2 >= beta2 * v_saved; check the loaded values through the optimizer's state dict
+    # BEFORE the discriminator's update touches its own
+    osd = tr.authenticator_opt.state_dict()
+    ref_state = ck["authenticator_opt"]["state"]
+    assert len(ref_state) == len(osd["state"])
+    for i, st in ref_state.items():
+        assert int(osd["state"][i]["step"]) == int(st["step"]) == 3
+        assert torch.allclose(osd["state"][i]["exp_avg_sq"].cpu(), st["exp_avg_sq"], rtol=0, atol=0), i
+    dres = G.au_train_step(trainer, real, gres[1], si)
+    # the fixture is the reference's own fp32 run: two fp32 implementations three Adam(beta1 = 0) updates in
+    assert relerr(gres[0], g["g_loss"]) < 1e-3 and relerr(gres[2], g["g_out"]) < 1e-3 and relerr(gres[1], g["fake"]) < 1e-3
+    for i, nm in enumerate(["loss", "loss_real", "loss_fake", "reg", "out_real", "out_fake"]):
+        assert relerr(dres[i], g["d_" + nm]) < 1e-3 or float(np.abs(g["d_" + nm]).max()) == 0.0, nm
+    assert int(tr.authenticator_opt.state_dict()["state"][0]["step"]) == 4
+
+
+class _LoopRecorder:
+    def __init__(self):
+        self.scalars, self.imgs = [], []
+
+    def add_scalar(self, category, k, v, global_step):
+        self.scalars.append([category, k, int(global_step), float(v)])
+
+    def add_imgs(self, imgs, category, k, global_step, nrow=5):
+        self.imgs.append([category, k, int(global_step), list(imgs.shape), float(imgs.double().sum()), float(imgs.double().abs().max())])
+
+
+class _MemDS(torch.utils.data.Dataset):
+    def __init__(self, tag, n_ex, m, n, k, c, s):
+        def img(name, i, t):
+            return T(np.clip(pf.normal("%s/%d/%s" % (tag, i, name), (t, c, s, s)) * 0.5, -1, 1), torch.float32)
+        self.ex = [{"real_sample": img("real", i, n), "leaked_sample": img("leaked", i, m), "si_sample": img("si", i, k),
+                    "class": i, "class_name": "c%d" % i} for i in range(n_ex)]
+
+    def __len__(self):
+        return len(self.ex)
+
+    def __getitem__(self, i):
+        return self.ex[i]
+
+
+def test_train_epoch_vs_reference_loop_golden(monkeypatch):
+    """tests/golden/loop.json is what the REFERENCE's train_epoch / eval_step / sample_and_save_imgs
+    (training/gim_img_training.py:23-73, 98-154, 186-354) logged over two epochs of two iterations on a fixed in-memory dataset,
+    with every cadence firing (n_au_steps = 2, eval / image dumps / encoding statistics every 2nd step, checkpoints every 3rd):
+    the product's loop must log the same keys at the same global steps with the same values, dump the same images, save at the
+    same steps and leave the same state."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    from optimalstrategiesagainstgenerativeattacks_amd import gim_img_training as gt
+    import tempfile
+    ref = load_json("loop.json")
+    c = ref["config"]
+    tag = "loop"
+    au, im = _product_models(tag, "16_1_32")
+    train_ds = _MemDS(tag + "/train", c["n_train"], c["m"], c["n"], c["k"], c["c"], c["s"])
+    val_ds = _MemDS(tag + "/val", c["n_val"], c["m"], c["n"], c["k"], c["c"], c["s"])
+    rec = _LoopRecorder()
+    saves = []
+    calls = {"n": 0}
+    real_randn = torch.randn
+
+    def fake_randn(*size, **kw):   # z of call i = the portable normal the reference's run got (models/gim_img_models.py:374)
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+        z = T(pf.normal("%s/z%d" % (tag, calls["n"]), shape), torch.float32)
+        calls["n"] += 1
+        return z.to(kw.get("device", "cpu"))
+    monkeypatch.setattr(torch, "randn", fake_randn)
+    with tempfile.TemporaryDirectory() as td:
+        tr = G.GIMImgTrainer(td, c["m"], c["n"], c["k"], au, im, au_lr=c["au_lr"], im_lr=c["im_lr"], env_noise_mapping_lr=c["noise_lr"],
+                             lr_milestones=tuple(c["milestones"]), lr_gamma=c["gamma"], reg_param=0.0)
+        orig_save = tr.save
+        tr.save = lambda epoch: (saves.append([int(tr.global_step), int(epoch)]), orig_save(epoch=epoch))[1]
+        trainer = G.DataParallelMock(tr)
+        torch.manual_seed(c["seed"])
+        for ep in range(c["n_epochs"]):
+            gt.train_epoch(device=dev(), logger=rec, epoch=ep, trainer=trainer, train_ds=train_ds, val_ds=val_ds,
+                           train_batch_size=c["train_batch_size"], val_batch_size=c["val_batch_size"], num_workers=0,
+                           save_every=c["save_every"], eval_every=c["eval_every"], save_imgs_every=c["save_imgs_every"],
+                           train_eval_indices=c["train_eval_indices"], val_eval_indices=c["val_eval_indices"],
+                           tb_log_every=c["tb_log_every"], tb_log_enc_every=c["tb_log_enc_every"], n_au_steps=c["n_au_steps"])
+        ckpts = sorted(os.listdir(os.path.join(td, "ckpts")))
+    monkeypatch.setattr(torch, "randn", real_randn)
+    assert calls["n"] == ref["n_randn_calls"]
+    assert saves == ref["saves"] and ckpts == ref["ckpt_files"] and tr.global_step == ref["final_global_step"]
+    # scalars: same (category, key, step) multiset; values at the north_star tolerance (accuracies and learning rates exact)
+    want = {(a, b, s_): v for a, b, s_, v in ref["scalars"]}
+    got = {(a, b, s_): v for a, b, s_, v in rec.scalars}
+    assert len(want) == len(ref["scalars"]) and len(got) == len(rec.scalars), "a key logged twice at one step"
+    assert set(got) == set(want), (sorted(set(got) ^ set(want))[:6])
+    for key, v in want.items():
+        if key[0] == "lr":
+            assert abs(got[key] - v) < 1e-12, key
+        elif "acc" in key[0]:
+            assert abs(got[key] - v) < 1e-6, (key, got[key], v)
+        else:
+            assert abs(got[key] - v) <= 1e-3 * abs(v) + 1e-6, (key, got[key], v)
+    # image dumps: same events in the same order, same content
+    assert [e[:4] for e in rec.imgs] == [e[:4] for e in ref["imgs"]]
+    for a, b in zip(rec.imgs, ref["imgs"]):
+        assert abs(a[4] - b[4]) <= 1e-3 * abs(b[4]) + 1e-3 * (b[3][-1] * b[3][-2]) ** 0.5 and abs(a[5] - b[5]) < 1e-3, (a, b)
+    au_walk = _noise_walk(tr.authenticator_opt, au.named_parameters(), 4, c["au_lr"])
+    im_walk = _noise_walk(tr.impersonator_opt, im.named_parameters(), 2, c["im_lr"])
+    _assert_final_state(au, ref["au_final"], au_walk, "authenticator after the loop")
+    _assert_final_state(im, ref["im_final"], im_walk, "impersonator after the loop")
+
+
+def test_episode_bank_vs_reference_dataset_golden():
+    """tests/golden/data.npz: example dicts returned by the REFERENCE's ImgGIMDataSet.__getitem__ (data_handling/img_datasets.py:
+    68-103) reading PNG files of the uint8 bank in the fixture, with the bank index and flip flag of every returned image.
+    EpisodeBank serves the same bank from HBM: gim_episode_gather on those indices / flags returns the reference's tensors BIT
+    FOR BIT (ToTensor, adjust_dynamic_range :270-276, horizontal flip), and the container-level contract is the reference's
+    (length, class filter :59-61, index -> class, set sizes, distinct images of one class)."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    g = load_npz("data.npz")
+    meta = load_json("data.json")
+    c = meta["config"]
+    imgs = torch.from_numpy(g["bank"]).to(dev())
+    offs = g["offsets"]
+    bank = G.EpisodeBank(imgs, offs, m=c["m"], n=c["n"], k=c["k"], example_cnt_per_class=c["example_cnt_per_class"], mirror=True, seed=3)
+    assert len(bank) == int(g["len"]) and bank.n_classes == int(g["n_classes"])
+    for e, ex in enumerate(meta["examples"]):
+        assert ex["class"] == ex["index"] // c["example_cnt_per_class"]
+        mine = bank[ex["index"]]
+        assert mine["class"] == ex["class"]
+        seen = []
+        for part, t in (("leaked_sample", c["m"]), ("real_sample", c["n"]), ("si_sample", c["k"])):
+            ref = g["ex%d/%s" % (e, part)]
+            src, flip = g["ex%d/%s/src" % (e, part)], g["ex%d/%s/flip" % (e, part)]
+            got = bank.gather(src, flip).cpu().numpy()
+            assert got.dtype == ref.dtype and np.array_equal(got, ref), (e, part)
+            assert tuple(mine[part].shape) == ref.shape == (t, c["C"], c["S"], c["S"])
+            seen += src.tolist()
+        cls = ex["bank_class"]
+        assert len(set(seen)) == c["m"] + c["n"] + c["k"] and all(offs[cls] <= v < offs[cls + 1] for v in seen)
+    assert np.array_equal(bank.gather(np.array([0, 1], dtype=np.int32), np.zeros(2, dtype=np.uint8)).cpu().numpy(), g["adr/out"].transpose(0, 3, 1, 2))

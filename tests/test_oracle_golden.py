@@ -242,3 +242,88 @@ def test_gaussian_toy_game_trainer(tag, reg):
     for kk in im:
         if not kk.startswith("out_mlp"):
             assert relerr(im[kk], g["%s/final/im/%s" % (tag, kk)]) < 1e-9, kk
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round-2 fixtures: sub-networks on their own, gradient TENSOR samples at a benchmark shape, the dataset sample contract
+# ------------------------------------------------------------------------------------------------------------------
+SUBNETS = {
+    "encoder": (dict(x=(3, 1, 16, 16)), lambda sd, x: go.encoder(sd, "", x, True)),
+    "envdecoder": (dict(x=(3, 32)), lambda sd, x: go.env_decoder(sd, "", x, True)),
+    "img2img": (dict(x=(3, 2, 16, 16), style=(3, 32)), lambda sd, x, style: go.img2img(sd, "", x, style, True)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SUBNETS))
+def test_subnet_matches_reference(name):
+    """Encoder / EnvDecoder / AdaInImage2Image alone: the oracle against the reference's fp64 run."""
+    g = load_npz("subnets.npz")
+    inputs, fn = SUBNETS[name]
+    ks = [(k[len(name) + 3:], g[k].shape) for k in g.files if k.startswith(name + "/g/") or k.startswith(name + "/b/")]
+    sd = filled_sd(ks, name + "/")
+    go.set_requires_grad(sd)
+    xs = {k: T(pf.normal("%s/%s" % (name, k), s)).requires_grad_() for k, s in inputs.items()}
+    y = fn(sd, **xs)
+    assert relerr(y, g[name + "/y"]) < 1e-9
+    (y * T(pf.uniform(name + "/r", tuple(y.shape)))).sum().backward()
+    for k, x in xs.items():
+        assert relerr(x.grad, g["%s/d_%s" % (name, k)], atol=1e-9) < 1e-7, k
+    gmax = max(float(np.linalg.norm(g[k])) for k in g.files if k.startswith(name + "/g/"))
+    for k in g.files:
+        if k.startswith(name + "/g/"):
+            assert relerr(sd[k[len(name) + 3:]].grad, g[k], atol=1e-9 * gmax) < 1e-6, k
+        if k.startswith(name + "/b/"):
+            assert relerr(sd[k[len(name) + 3:]], g[k]) < TOL, k
+
+
+def test_bench_shape_32_gradient_tensor_samples():
+    """nets_om32_f64_grads.npz: strided samples of whole gradient tensors (G step and D step, 32x32x1, style 512) from the
+    reference - position-sensitive, unlike the per-tensor norms of nets_om32_f64.json."""
+    tag = "om32_f64"
+    gs = load_npz("nets_%s_grads.npz" % tag)
+    c = load_json("nets_%s.json" % tag)["config"]
+    au, im = _models(tag, "32_1_512", torch.float64)
+    leaked, real, si, z = episode(tag, c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"], torch.float64)
+    loss, fake, out = go.impersonator_forward(au, im, leaked, si, c["n"], z, True, True)
+    loss.mean().backward()
+    n = 0
+    for k in gs.files:
+        if k.startswith("g/"):
+            _, stride, name = k.split("/", 2)
+            assert relerr(im[name].grad.reshape(-1)[::int(stride)], gs[k]) < 1e-6, k   # the fixture stores float32
+            n += 1
+    for sd in (au, im):
+        for p in sd.values():
+            p.grad = None
+    go.authenticator_forward(au, fake.detach(), real, si, True, 0.0)[0].mean().backward()
+    for k in gs.files:
+        if k.startswith("d/"):
+            _, stride, name = k.split("/", 2)
+            assert relerr(au[name].grad.reshape(-1)[::int(stride)], gs[k]) < 1e-6, k
+            n += 1
+    assert n == len(gs.files) == 10
+
+
+def test_dataset_contract_fixture_pins_the_numpy_restatement():
+    """tests/golden/data.npz (the reference's ImgGIMDataSet on PNG files of the bank): the value map the GPU gather kernel is
+    tested against - float32(u8) / 255 * 2 + (-1), horizontal flip along W - reproduces the reference's tensors bit for bit,
+    and the container contract holds (class filter, index -> class, distinct images of one class, set sizes)."""
+    g = load_npz("data.npz")
+    meta = load_json("data.json")
+    c = meta["config"]
+    bank, offs = g["bank"], g["offsets"]
+    assert int(g["n_classes"]) == sum(1 for s in c["sizes"] if s >= c["m"] + c["n"] + c["k"]) == 3
+    assert int(g["len"]) == 3 * c["example_cnt_per_class"]
+    for e, ex in enumerate(meta["examples"]):
+        assert ex["class"] == ex["index"] // c["example_cnt_per_class"]
+        seen = []
+        for part, t in (("leaked_sample", c["m"]), ("real_sample", c["n"]), ("si_sample", c["k"])):
+            ref = g["ex%d/%s" % (e, part)]
+            assert ref.shape == (t, c["C"], c["S"], c["S"]) and ref.dtype == np.float32 and np.abs(ref).max() <= 1.0
+            for i, (src, flip) in enumerate(zip(g["ex%d/%s/src" % (e, part)], g["ex%d/%s/flip" % (e, part)])):
+                img = bank[src][:, ::-1] if flip else bank[src]
+                mine = (img.astype(np.float32) / np.float32(255.0)) * np.float32(2.0) + np.float32(-1.0)
+                assert np.array_equal(mine.transpose(2, 0, 1), ref[i]), (e, part, i)
+                seen.append(int(src))
+        cls = ex["bank_class"]
+        assert len(set(seen)) == len(seen) == c["m"] + c["n"] + c["k"] and all(offs[cls] <= v < offs[cls + 1] for v in seen)
