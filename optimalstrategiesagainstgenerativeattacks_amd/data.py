@@ -17,13 +17,15 @@ from . import _lib
 from ._lib import check
 
 
-class EpisodeBank(torch.utils.data.Dataset):
-    def __init__(self, images_u8, class_offsets, m, n, k, example_cnt_per_class=1, mirror=True, class_names=None, seed=0):
-        """images_u8: uint8 [n_img, S, S, C] (NHWC) on the GPU, images of one class contiguous;
-        class_offsets: [n_classes + 1] start offsets into images_u8."""
-        if not (images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.is_contiguous()):
-            raise RuntimeError("EpisodeBank: images must be a contiguous CUDA uint8 [n_img, S, S, C] tensor (no CPU path)")
-        self.bank = images_u8
+class EpisodeSampler:
+    """Host side of the pipeline (no tensors): which images make up which episode, for which rank.
+
+    Two independent generators.  The epoch SHUFFLE must be the same permutation on every rank of a data-parallel job (each rank
+    slices its share out of every global batch), while the per-episode image DRAWS differ per rank and consume a data-dependent
+    number of values (class sizes differ): drawn from one generator they would knock the ranks' shuffles out of step after the
+    first epoch, and ranks would then train on overlapping / missing episodes."""
+
+    def __init__(self, class_offsets, m, n, k, example_cnt_per_class=1, mirror=True, seed=0):
         self.offsets = np.asarray(class_offsets, dtype=np.int64)
         self.m, self.n, self.k = m, n, k
         self.t = m + n + k
@@ -33,23 +35,63 @@ class EpisodeBank(torch.utils.data.Dataset):
         self.n_classes = int(keep.sum())
         self.example_cnt_per_class = example_cnt_per_class
         self.mirror = mirror
-        self.class_names = class_names
-        self.rng = np.random.default_rng(seed)
-        self.S, self.C = images_u8.shape[1], images_u8.shape[3]
+        self.seed = seed
+        self.shuffle_rng = np.random.default_rng([seed, 0x5EED])
+        self._draw_rngs = {}
 
     def __len__(self):
         return self.n_classes * self.example_cnt_per_class
 
-    # ---- index sampling (host) ----
-    def _draw(self, cls_rows):
-        """[B, t] image indices (distinct within a row) and [B, t] flip flags for the given class rows."""
+    def _rng(self, rank):
+        if rank not in self._draw_rngs:
+            self._draw_rngs[rank] = np.random.default_rng([self.seed, 0xD4A3, rank])
+        return self._draw_rngs[rank]
+
+    def draw(self, cls_rows, rank=0):
+        """[B, t] image indices (distinct within a row) and [B, t] flip flags for the given class rows (rank's own generator)."""
+        rng = self._rng(rank)
         B = len(cls_rows)
         idx = np.empty((B, self.t), dtype=np.int32)
         for b, c in enumerate(cls_rows):
             lo, hi = self.offsets[self.class_ids[c]], self.offsets[self.class_ids[c] + 1]
-            idx[b] = lo + self.rng.choice(hi - lo, size=self.t, replace=False)   # random.sample (img_datasets.py:79)
-        flip = (self.rng.random((B, self.t)) < 0.5) if self.mirror else np.zeros((B, self.t), dtype=bool)
+            idx[b] = lo + rng.choice(hi - lo, size=self.t, replace=False)   # random.sample (img_datasets.py:79)
+        flip = (rng.random((B, self.t)) < 0.5) if self.mirror else np.zeros((B, self.t), dtype=bool)
         return idx, flip.astype(np.uint8)
+
+    def epoch_rows(self, batch_size, shuffle, drop_last=True, rank=0, world=1):
+        """Per global batch of one epoch: the class rows of THIS rank's slice (what DataLoader(shuffle, drop_last) + the
+        episode-dim scatter of nn.DataParallel give, training/gim_img_training.py:210,409)."""
+        assert batch_size % world == 0, "the global batch must divide by the number of ranks (training/utils.py:167-171)"
+        order = np.arange(len(self))
+        if shuffle:
+            self.shuffle_rng.shuffle(order)     # identical on every rank: same seed, and nothing else draws from this generator
+        n_full = len(order) // batch_size if drop_last else -(-len(order) // batch_size)
+        per = batch_size // world
+        for i in range(n_full):
+            rows = order[i * batch_size:(i + 1) * batch_size] // self.example_cnt_per_class
+            yield list(rows[rank * per:(rank + 1) * per])
+
+
+class EpisodeBank(torch.utils.data.Dataset):
+    def __init__(self, images_u8, class_offsets, m, n, k, example_cnt_per_class=1, mirror=True, class_names=None, seed=0):
+        """images_u8: uint8 [n_img, S, S, C] (NHWC) on the GPU, images of one class contiguous;
+        class_offsets: [n_classes + 1] start offsets into images_u8."""
+        if not (images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.is_contiguous()):
+            raise RuntimeError("EpisodeBank: images must be a contiguous CUDA uint8 [n_img, S, S, C] tensor (no CPU path)")
+        self.bank = images_u8
+        self.sampler = EpisodeSampler(class_offsets, m, n, k, example_cnt_per_class, mirror, seed)
+        self.offsets, self.class_ids, self.n_classes = self.sampler.offsets, self.sampler.class_ids, self.sampler.n_classes
+        self.m, self.n, self.k, self.t = m, n, k, m + n + k
+        self.example_cnt_per_class = example_cnt_per_class
+        self.mirror = mirror
+        self.class_names = class_names
+        self.S, self.C = images_u8.shape[1], images_u8.shape[3]
+
+    def __len__(self):
+        return len(self.sampler)
+
+    def _draw(self, cls_rows, rank=0):
+        return self.sampler.draw(cls_rows, rank)
 
     def gather(self, idx, flip):
         """float [len(idx), C, S, S] in [-1, 1] from flat image indices / flip flags (numpy or tensors)."""
@@ -62,9 +104,9 @@ class EpisodeBank(torch.utils.data.Dataset):
                                              self.S, self.S, self.C, torch.cuda.current_stream().cuda_stream), "episode_gather")
         return out
 
-    def batch(self, cls_rows):
+    def batch(self, cls_rows, rank=0):
         """One collated batch (dict of device tensors, the DataLoader's output format) for the given class rows."""
-        idx, flip = self._draw(cls_rows)
+        idx, flip = self.sampler.draw(cls_rows, rank)
         B = len(cls_rows)
         x = self.gather(idx, flip).view(B, self.t, self.C, self.S, self.S)
         m, n = self.m, self.n
@@ -86,14 +128,8 @@ class EpisodeBank(torch.utils.data.Dataset):
         """Iterator over collated device batches: what ``DataLoader(ds, batch_size, shuffle, drop_last)`` yields, without
         the host round trip; with world > 1 each rank takes its own slice of every global batch (episodes are the
         data-parallel unit)."""
-        order = np.arange(len(self))
-        if shuffle:
-            self.rng.shuffle(order)
-        n_full = len(order) // batch_size if drop_last else -(-len(order) // batch_size)
-        per = batch_size // world
-        for i in range(n_full):
-            rows = order[i * batch_size:(i + 1) * batch_size] // self.example_cnt_per_class
-            yield self.batch(list(rows[rank * per:(rank + 1) * per]))
+        for rows in self.sampler.epoch_rows(batch_size, shuffle, drop_last, rank, world):
+            yield self.batch(rows, rank)
 
     def num_batches(self, batch_size, drop_last=True):
         return len(self) // batch_size if drop_last else -(-len(self) // batch_size)

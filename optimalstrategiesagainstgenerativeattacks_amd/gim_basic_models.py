@@ -3,7 +3,8 @@
 
 On the hot path the three statistics of both sample sets and the concat to the [B, 5120] head input are
 ONE fused operator (``ops.head_cat``); the classes below keep the reference's module tree (state-dict key
-``fc.stat.model.*``) and expose the per-sample FC features that operator needs.
+``fc.stat.model.*``), expose the per-sample FC features that operator needs, and implement every ``forward`` of
+the reference on the same kernels (``gim_set_stats_fwd / _bwd``).
 """
 import torch.nn as nn
 
@@ -26,7 +27,8 @@ class GIMStdStat(nn.Module):
         self.n_stats = 1
 
     def forward(self, x):
-        raise NotImplementedError("custom_std is only available fused (ops.head_cat)")
+        """models/gim_basic_models.py:37-51: sqrt(unbiased variance over the set + 1e-8), zeros for a one-element set."""
+        return mb.custom_std(x)
 
 
 class GIMFCStat(nn.Module):
@@ -55,4 +57,6 @@ class GIMMeanStdFcStat(nn.Module):
         self.fc = GIMFCStat(style_dim=style_dim, n_stats=fc_n_stats, hidden_layers=fc_hidden_layers)
 
     def forward(self, x):
-        raise NotImplementedError("use GIMFaceDis.forward: the statistics are fused into ops.head_cat")
+        """models/gim_basic_models.py:169-172: cat(mean, std, mean of the FC features) of ONE sample set [B, t, D] -> [B, n_stats*D]
+        (one fused operator; GIMFaceDis.forward uses the two-set form ops.head_cat, which also writes the source means)."""
+        return ops.stat_cat(x, self.fc.per_sample(x))

@@ -217,14 +217,14 @@ class AdaInImage2Image(nn.Module):
         if _use_side_streams(x):
             cur = torch.cuda.current_stream()
             side = _side_streams(x.device)[0]
-            side.wait_stream(cur)
+            ops.stream_wait(side, cur)
             with torch.cuda.stream(side):
                 svs_res = [b.style_vectors(style) for b in self.adain_res_block.res_blocks]
                 svs_up = [b.style_vectors(style) for b in self.adain_up_block.up_blocks]
             style.record_stream(side)
         x = self.down_block(x)
         if svs_res is not None:
-            cur.wait_stream(side)
+            ops.stream_wait(cur, side)
             for sv in svs_res + svs_up:
                 for t in sv:
                     t.record_stream(cur)
@@ -301,7 +301,7 @@ class GIMFaceAuthenticator(nn.Module):
             for i, smp in enumerate(samples):
                 st = streams[e * len(samples) + i] if per_sample else streams[e]
                 if per_sample or i == 0:
-                    st.wait_stream(cur)
+                    ops.stream_wait(st, cur)
                 with torch.cuda.stream(st):
                     f = _encode_sample(enc, smp)
                 f.record_stream(cur)  # produced on the side stream, consumed by the head on the current stream
@@ -309,7 +309,7 @@ class GIMFaceAuthenticator(nn.Module):
                 feats.append(f)
             outs.append(feats)
         for st in streams:
-            cur.wait_stream(st)
+            ops.stream_wait(cur, st)
         return outs[0], outs[1]
 
     def src_encode_sample(self, sample):
@@ -348,7 +348,7 @@ class GIMFaceImpersonator(nn.Module):
         if _use_side_streams(leaked):
             cur = torch.cuda.current_stream()
             side = _side_streams(leaked.device)[1]
-            side.wait_stream(cur)
+            ops.stream_wait(side, cur)
             with torch.cuda.stream(side):
                 src = ops.mean_dim1(self.src_encoder(leaked).view(B, m, -1))
             leaked.record_stream(side)
@@ -361,7 +361,7 @@ class GIMFaceImpersonator(nn.Module):
         noisy_env = ops.noise_combine(env, w, remove_noise_mean)
         env_img = self.env_decoder(noisy_env.view(B * n, -1))
         if side is not None:
-            cur.wait_stream(side)
+            ops.stream_wait(cur, side)
             src.record_stream(cur)
         first = leaked.view(B, m, S, S, C)[:, 0]
         x = ops.concat2(env_img, first, n)

@@ -96,7 +96,7 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
                                                 si_sample=si_sample, **({} if z is None else {"z": z}))
     loss = loss.mean()
     fake_d = fake_sample.detach()
-    dstream.wait_stream(cur)            # lane 1 forks here: everything up to the generator's forward is visible to it
+    ops.stream_wait(dstream, cur)            # lane 1 forks here: everything up to the generator's forward is visible to it
     for t in (fake_d, real_sample, si_sample):
         t.record_stream(dstream)
 
@@ -125,7 +125,7 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
     if defer_join:
         ops.defer_join(dstream)
     else:
-        cur.wait_stream(dstream)
+        ops.stream_wait(cur, dstream)
     for t in au:
         t.record_stream(cur)
     return im, au
@@ -135,6 +135,8 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
 # the caller loop (training/gim_img_training.py:24-74, 98-154, 186-354, 356-441)
 # --------------------------------------------------------------------------------------------------------------------
 def save_imgs(logger, img_sample, category, k, global_step):
+    if logger is None:   # a rank other than 0 of a data-parallel job: it ran the forward (see train_epoch) and logs nothing
+        return
     imgs_for_save = ((img_sample[0].clamp(-1, 1) + 1) / 2.0).cpu()
     logger.add_imgs(imgs=imgs_for_save, category=category, k=k, global_step=global_step)
 
@@ -271,9 +273,13 @@ def train_epoch(device, logger, epoch, trainer, train_ds, val_ds, train_batch_si
 
         if global_step % save_every == 0 and rank == 0:
             trainer.module.save(epoch=epoch)
-        if global_step % save_imgs_every == 0 and rank == 0:
-            sample_and_save_imgs(device=device, logger=logger, trainer=trainer, ds=train_ds, ds_prefix='train', indices=train_eval_indices, dbg=dbg)
-            sample_and_save_imgs(device=device, logger=logger, trainer=trainer, ds=val_ds, ds_prefix='val', indices=val_eval_indices, dbg=dbg)
+        if global_step % save_imgs_every == 0:
+            # EVERY rank runs these generator forwards (only rank 0 writes the images): the generator is in train mode here, as in
+            # the reference, so each forward runs one spectral-norm power iteration per conv - a rank that skipped them would
+            # carry different u / v buffers, hence different sigma, from then on
+            lg = logger if rank == 0 else None
+            sample_and_save_imgs(device=device, logger=lg, trainer=trainer, ds=train_ds, ds_prefix='train', indices=train_eval_indices, dbg=dbg)
+            sample_and_save_imgs(device=device, logger=lg, trainer=trainer, ds=val_ds, ds_prefix='val', indices=val_eval_indices, dbg=dbg)
         if global_step % eval_every == 0:
             eval_step(device=device, trainer=trainer, ds=val_ds, logger=logger, batch_size=val_batch_size)
     ops.join_lanes()

@@ -19,7 +19,9 @@ class GraphedGimStep:
     Outputs are static tensors overwritten by the next replay.  Parameters, Adam state, spectral-norm buffers are
     updated in place exactly as by the eager ``gim_step``; the host-side step counters are advanced here."""
 
-    def __init__(self, trainer, leaked, real, si, z, warmup=3):
+    def __init__(self, trainer, leaked, real, si, z, warmup=3, overlap=False):
+        """overlap: capture the two-lane protocol of gim_step (the discriminator step on its own stream next to the generator's
+        backward) instead of the sequential one."""
         self.trainer = trainer
         self.mod = trainer.module
         self.static = [t.clone() for t in (leaked, real, si, z)]
@@ -28,18 +30,27 @@ class GraphedGimStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                gim_step(trainer, *self.static[:3], z=self.static[3], overlap=False)
+                gim_step(trainer, *self.static[:3], z=self.static[3], overlap=overlap)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):
             opt._push_lrs()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = gim_step(trainer, *self.static[:3], z=self.static[3], overlap=False)
+            self.out = gim_step(trainer, *self.static[:3], z=self.static[3], overlap=overlap)
         # the capture pass itself advanced the host-side counters once without running: undo nothing, but note
         # that parameters were NOT changed by the capture (kernels are only recorded)
         for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):
             opt.note_steps(-1)
+        # With the counters restored, the caches of tensors derived from the weights (folded weights per conv, transposed weights
+        # of the bf16x3 dgrad) carry the keys of tensors that the capture only RECORDED, never computed: an eager forward before
+        # the first replay would read them.  Drop them (the graph keeps its own references and recomputes them on every replay).
+        from . import model_blocks as mb
+        from . import ops
+        for m_ in list(self.mod.authenticator.modules()) + list(self.mod.impersonator.modules()):
+            if isinstance(m_, mb.SNConv2d):
+                m_._fold_cache = (None, None, None, None, False)
+        ops._WT_CACHE.clear()
 
     def __call__(self, leaked, real, si, z):
         for dst, src in zip(self.static, (leaked, real, si, z)):

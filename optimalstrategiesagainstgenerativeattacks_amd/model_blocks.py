@@ -110,7 +110,7 @@ class SNConv2d(nn.Module):
         self.register_buffer("weight_v", v)
 
         self._sn_queue = collections.deque()  # (sigma, u, v) triples precomputed by an SNPlan round
-        self._fold_cache = (None, None, None, None)   # ((storage, version, optimizer epoch), folded weights F, ready event, stream)
+        self._fold_cache = (None, None, None, None, False)   # ((storage, version, optimizer epoch), folded weights F, ready event, stream, recorded in a capture)
 
     def folded(self):
         """The (k+1)^2-tap folded weights for the pool / sub-pixel forms, recomputed only when weight_orig changed
@@ -123,9 +123,12 @@ class SNConv2d(nn.Module):
             with torch.no_grad():
                 f = ops._folded(ops.weight_phys(w), self.out_channels, self.in_channels, self.kernel_size)
             # other streams (one per encoder pass) reuse F: they wait for the kernel that wrote it
-            self._fold_cache = (key, f, torch.cuda.current_stream().record_event(), raw)
+            self._fold_cache = (key, f, torch.cuda.current_stream().record_event(), raw, torch.cuda.is_current_stream_capturing())
         elif self._fold_cache[3] != raw:
-            torch.cuda.current_stream().wait_event(self._fold_cache[2])
+            cur = torch.cuda.current_stream()
+            if self._fold_cache[4] or not torch.cuda.is_current_stream_capturing():   # see ops.WgradQueue.take
+                cur.wait_event(self._fold_cache[2])
+            self._fold_cache[1].record_stream(cur)   # F was allocated on another stream: keep its memory until this one is done with it
         return self._fold_cache[1]
 
     def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False):

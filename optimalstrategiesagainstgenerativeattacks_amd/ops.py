@@ -200,12 +200,28 @@ class WgradQueue:
         self.cache = collections.OrderedDict()   # job-table signature -> device tables (G / D backward, buffer parities)
         self.enabled = os.environ.get("GIM_WGRAD_IMMEDIATE") is None
 
+    @staticmethod
+    def _zeroed_mark():
+        """[event after the zero-fill just issued on the current stream, streams ordered behind it, recorded inside a capture]."""
+        return [torch.cuda.current_stream().record_event(), {_stream()}, torch.cuda.is_current_stream_capturing()]
+
     def take(self, n, device):
         """n zeroed floats (64-float aligned) that stay valid until the flush."""
         n = (n + 63) & ~63
+        raw = _stream()
         if not self.pages or self.pages[-1][1] + n > self.pages[-1][0].numel():
-            self.pages.append([torch.zeros(max(n, self.PAGE), device=device, dtype=torch.float32), 0])
+            # the zero-fill runs on the allocating stream; every OTHER stream that later adds into this page first waits for it
+            page = torch.zeros(max(n, self.PAGE), device=device, dtype=torch.float32)
+            self.pages.append([page, 0] + self._zeroed_mark())
         pg = self.pages[-1]
+        if raw not in pg[3]:
+            cur = torch.cuda.current_stream()
+            # (an event recorded BEFORE a hipGraph capture began is not waited for inside the capture: that work has completed -
+            # GraphedGimStep synchronizes before it captures - and a captured wait on an un-captured event is not a graph edge)
+            if pg[4] or not torch.cuda.is_current_stream_capturing():
+                cur.wait_event(pg[2])
+            pg[0].record_stream(cur)
+            pg[3].add(raw)
         ptr = pg[0].data_ptr() + 4 * pg[1]
         pg[1] += n
         return ptr
@@ -227,8 +243,7 @@ class WgradQueue:
             return
         cur = torch.cuda.current_stream()
         for st in self.streams:   # slots were written on the encoders' side streams too
-            if st != cur:
-                cur.wait_stream(st)
+            stream_wait(cur, st)
         device = self.pages[0][0].device
         sig = tuple(self.jobs)
         dev_tabs = self.cache.get(sig)
@@ -261,12 +276,14 @@ class WgradQueue:
               "wgrad_finish_batched")
         if len(self.pages) > 1:  # first backward of a new shape: merge into one page for the next pass
             total = sum(pg[1] for pg in self.pages)
-            self.pages = [[torch.zeros(total + (total >> 3), device=device, dtype=torch.float32), 0]]
+            self.pages = [[torch.zeros(total + (total >> 3), device=device, dtype=torch.float32), 0] + self._zeroed_mark()]
             self.cache.clear()
         else:
             pg = self.pages[0]
             pg[0][:pg[1]].zero_()
             pg[1] = 0
+            # the re-zeroing runs on the flushing stream; the next pass's first user on every other stream waits for it
+            pg[2:] = self._zeroed_mark()
         self.jobs, self.keep, self.streams = [], [], set()
 
 
@@ -286,6 +303,7 @@ def reset_wgrad_queues():
                 if pg[1]:
                     pg[0][:pg[1]].zero_()
                     pg[1] = 0
+                    pg[2:] = q._zeroed_mark()
             q.jobs, q.keep, q.streams, q.cb_queued = [], [], set(), False
 
 
@@ -298,6 +316,15 @@ def _queue():
     if q is None:
         q = _QUEUES[_LANE[0]] = WgradQueue()
     return q
+
+
+def stream_wait(waiter, other):
+    """waiter.wait_stream(other), skipped when both are the same HIP stream.  The role -> stream map of gim_img_models aliases
+    roles onto shared streams (lane 1's first encoder runs on lane 1's own stream): a stream "waiting for itself" is a no-op in
+    eager execution, but inside a hipGraph capture it records an event on the capturing stream and then makes that same stream
+    wait for it - a self-edge in the captured graph (see graph.GraphedGimStep)."""
+    if waiter.cuda_stream != other.cuda_stream:
+        waiter.wait_stream(other)
 
 
 _PENDING_JOIN = []   # streams of lane-1 work the caller's stream has not waited for yet (gim_step(defer_join=True))
@@ -313,7 +340,7 @@ def join_lanes():
     if _PENDING_JOIN:
         cur = torch.cuda.current_stream()
         for st in _PENDING_JOIN:
-            cur.wait_stream(st)
+            stream_wait(cur, st)
         del _PENDING_JOIN[:]
 
 
@@ -426,11 +453,13 @@ def _transposed(lib, w, wk, Cout, Cin, KF):
         cur = torch.cuda.current_stream()
         wt = torch.empty(Cin * KF * KF * Cout, device=wk.device, dtype=torch.float32)
         check(lib.gim_conv2d_transpose_weights(_p(wk), _p(wt), Cout, Cin, KF, raw), "transpose_weights")
-        ent = (key, wt, cur.record_event(), raw, weakref.ref(w, lambda _r, slot=slot: _WT_CACHE.pop(slot, None)))
+        ent = (key, wt, cur.record_event(), raw, weakref.ref(w, lambda _r, slot=slot: _WT_CACHE.pop(slot, None)),
+               torch.cuda.is_current_stream_capturing())
         _WT_CACHE[slot] = ent
     elif ent[3] != raw:
         cur = torch.cuda.current_stream()
-        cur.wait_event(ent[2])
+        if ent[5] or not torch.cuda.is_current_stream_capturing():   # see WgradQueue.take
+            cur.wait_event(ent[2])
         ent[1].record_stream(cur)
     return ent[1]
 
@@ -1127,6 +1156,52 @@ class HeadCatFn(Function):
         bwd(4, ft, n, Df, o_te + 2 * De, None)
         bwd(5, fs, k, Df, o_se + 2 * De, None)
         return tuple(grads)
+
+
+class StatCatFn(Function):
+    """cat(mean(x, 1), custom_std(x), mean(fc, 1)) for x [B, t, D] and the per-sample FC features fc [B, t, Df] -> [B, 2 D + Df]
+    (GIMMeanStdFcStat.forward, models/gim_basic_models.py:152-172, as a standalone operator; the authenticator head uses the
+    two-set form HeadCatFn)."""
+
+    @staticmethod
+    def forward(ctx, x, fc):
+        lib = _lib.load()
+        x, fc = _req(x, "x"), _req(fc, "fc")
+        B, t, D = x.shape
+        Df = fc.shape[2]
+        L = 2 * D + Df
+        out = torch.empty((B, L), device=x.device, dtype=torch.float32)
+        st = _stream()
+        check(lib.gim_set_stats_fwd(_p(x), _p(out, 0), _p(out, D), B, t, D, L, L, st), "set_stats_fwd")
+        check(lib.gim_set_stats_fwd(_p(fc), _p(out, 2 * D), None, B, t, Df, L, L, st), "set_stats_fwd")
+        ctx.save_for_backward(x, fc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, fc = ctx.saved_tensors
+        dout = _req(dout, "dout")
+        B, t, D = x.shape
+        Df = fc.shape[2]
+        L = dout.shape[1]
+        st = _stream()
+        second = _second_order()
+        grads = [None, None]
+        for i, (src, Dn, o_mean, o_std) in enumerate(((x, D, 0, D), (fc, Df, 2 * D, None))):
+            if not ctx.needs_input_grad[i]:
+                continue
+            if second:
+                grads[i] = SetStatsBwdFn.apply(dout, src, o_mean, o_std)
+                continue
+            dx = torch.empty_like(src)
+            check(lib.gim_set_stats_bwd(_p(src), _p(dout, o_mean), (_p(dout, o_std) if o_std is not None else None), _p(dx),
+                                        B, t, Dn, L, L, st), "set_stats_bwd")
+            grads[i] = dx
+        return tuple(grads)
+
+
+stat_cat = StatCatFn.apply
 
 
 class SetStatsBwdFn(Function):

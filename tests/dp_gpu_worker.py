@@ -13,6 +13,7 @@ from tests.helpers import episode, filled_sd, load_keys  # noqa: E402
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    n_iters = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,13 +31,13 @@ def main():
     if world > 1:
         trainer.broadcast_parameters()
     outs = []
-    for it in range(2):
+    for it in range(n_iters):
         leaked, real, si, z = [t.float().to(dev) for t in episode("dpg/%d" % it, B, m, n, k, c, s, d)]
         if world > 1:
             leaked, real, si, z = trainer.shard(leaked, real, si, z)
         tr.do_global_step()
         gi, di = G.gim_step(trainer, leaked, real, si, z=z)
-        outs.append((gi[0].item(), di[0].item()))
+        outs.append((gi[0].item(), di[0].item(), di[4].item(), di[5].item()))
     torch.cuda.synchronize()
     if rank == 0:
         sd = {"au." + k_: v.cpu() for k_, v in au.state_dict().items()}

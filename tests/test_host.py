@@ -314,3 +314,32 @@ def test_library_sources_read_no_environment_and_keep_no_mutable_globals():
         for mt in re.finditer(r"^static\s+(?!inline|const|constexpr|thread_local|__device__|__global__|void|int\s+\w+\(|bool\s+\w+\(|Geo\s+\w+\(|"
                               r"WgPlan\s+\w+\(|size_t\s+\w+\(|float\s+\w+\(|long\s+long\s+\w+\()([^;{(]*)[;=]", src, re.M):
             raise AssertionError("%s: mutable file-scope static: %s" % (f, mt.group(0)))
+
+
+def test_episode_sampler_ranks_stay_in_step_over_epochs():
+    """Data-parallel episode sharding (training/gim_img_training.py:406-411 scatters the batch over devices): every rank's
+    process shuffles the SAME epoch order - also in later epochs, although each rank has drawn a different, data-dependent
+    number of random values for its own episodes in between (classes of unequal size) - and the rank slices of a global batch
+    are disjoint and complete."""
+    from optimalstrategiesagainstgenerativeattacks_amd.data import EpisodeSampler
+    sizes = [9, 30, 8, 17, 12, 25, 8, 40]
+    offs = [0]
+    for s_ in sizes:
+        offs.append(offs[-1] + s_)
+    world, bs = 2, 4
+    ranks = [EpisodeSampler(offs, 1, 3, 4, example_cnt_per_class=2, mirror=True, seed=7) for _ in range(world)]   # one per process
+    single = EpisodeSampler(offs, 1, 3, 4, example_cnt_per_class=2, mirror=True, seed=7)
+    for epoch in range(4):
+        per_rank = [list(r.epoch_rows(bs, True, True, rank, world)) for rank, r in enumerate(ranks)]
+        whole = list(single.epoch_rows(bs, True, True, 0, 1))
+        assert len(per_rank[0]) == len(per_rank[1]) == len(whole) == len(single) // bs
+        for i, rows in enumerate(whole):
+            assert per_rank[0][i] + per_rank[1][i] == rows, (epoch, i)     # the two slices ARE the global batch, in order
+        for rank, r in enumerate(ranks):                                     # each rank now draws its episodes (different counts)
+            for rows in per_rank[rank]:
+                idx, flip = r.draw(rows, rank)
+                assert idx.shape == (len(rows), 8) and all(len(set(row.tolist())) == 8 for row in idx)
+        single.draw(whole[0], 0)
+    a, _ = ranks[0].draw([1, 1], 0)
+    b, _ = ranks[1].draw([1, 1], 1)
+    assert not (a == b).all()      # ranks draw different images
