@@ -717,8 +717,9 @@ struct WgP {
     int atomic;        // 1: all pixel slices add into ONE pre-zeroed slab with float atomics (no reduce pass)
 };
 
-// VEC = 4: dY rows and gathered x rows are fetched as float4 (Cout % 4 == 0, Cin % 4 == 0, 16-byte aligned
-// bases); VEC = 1: scalar fallback (3- and 6-channel image layers, 1-channel Omniglot).
+// VA / VB = 4: the dY rows (A) / the gathered x rows (B) are fetched as float4 (their channel count % 4 == 0, 16-byte aligned
+// base); = 1: scalar fallback for that operand alone (3- and 6-channel image layers, 1-channel Omniglot: the 64-channel dY of
+// the first encoder conv still streams as float4 while its 3-channel input is gathered element by element).
 // Workgroups of the first column tile also produce the bias gradient sum_m dY[m][co] of their pixel slice from
 // the dY values they stream anyway (bias_slabs[slice][Cout]).
 // PREC 1 (bf16x3, see conv_igemm_kernel): the K dimension of this contraction is the PIXEL index, which is not contiguous for a
@@ -754,21 +755,22 @@ __device__ __forceinline__ void x3_split_store_planes(char* dst, int plane_bytes
     *reinterpret_cast<u32x2*>(dst + 2 * plane_bytes) = lo;
 }
 
-template <int BM, int BN, int TM, int TN, int VEC, bool FASTB, int PREC = 0>
+template <int BM, int BN, int TM, int TN, int VA, int VB, bool FASTB, int PREC = 0>
 __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP p) {
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr bool X3 = PREC == 1;
-    static_assert(!X3 || VEC == 4, "bf16x3 wgrad: vector path only");
-    constexpr int AU = BM / VEC, BU = BN / VEC;                 // load units per tile row
+    static_assert(!X3 || (VA == 4 && VB == 4), "bf16x3 wgrad: vector path only");
+    static_assert(!FASTB || VB == 4, "fast B addressing: vector path only");
+    constexpr int AU = BM / VA, BU = BN / VB;                   // load units per tile row
     constexpr int A_RSTEP = 256 / AU, B_RSTEP = 256 / BU;       // tile rows covered per pass
     constexpr int A_PER = (BK + A_RSTEP - 1) / A_RSTEP, B_PER = (BK + B_RSTEP - 1) / B_RSTEP;
     // bf16x3 image: bytes per k-row (stride = 64 mod 128), per plane, per buffer
     constexpr int RSA = ((BM * 2) % 128 == 64) ? BM * 2 : BM * 2 + 64, RSB = ((BN * 2) % 128 == 64) ? BN * 2 : BN * 2 + 64;
     constexpr int PLA = BK * RSA, PLB = BK * RSB;
     constexpr int A_FLOATS = X3 ? 3 * PLA / 4 : BK * BM, B_FLOATS = X3 ? 3 * PLB / 4 : BK * BN;
-    static_assert(!X3 || 2 * A_FLOATS >= 256 * VEC, "bias reduction scratch");
+    static_assert(!X3 || 2 * A_FLOATS >= 256 * VA, "bias reduction scratch");
     __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
 
@@ -779,9 +781,9 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     const int mend = min(p.M, mbeg + p.mper);
     const int He = g.Hin << g.ups, We = g.Win << g.ups;
 
-    const int ac = (t % AU) * VEC, ak = t / AU;
+    const int ac = (t % AU) * VA, ak = t / AU;
     const bool a_cok = (co0 + ac) < p.Cout;
-    const int bc = (t % BU) * VEC, bk = t / BU;
+    const int bc = (t % BU) * VB, bk = t / BU;
     const int j = j0 + bc;
     const bool b_jok = j < p.Kcols;
     const int tap = b_jok ? j / p.Cin : 0;
@@ -790,25 +792,27 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     const int dh = ta + g.off_y, dw = tb + g.off_x;
     const bool do_bias = p.bias_slabs != nullptr && blockIdx.x == 0;
 
-    // ---- VEC == 4 fast addressing (tools/micro/mfma_valu.hip: VALU work is paid in matrix-pipe time) ----
+    // ---- vector-path fast addressing (tools/micro/mfma_valu.hip: VALU work is paid in matrix-pipe time) ----
     // A (dy rows): buffer resource whose BASE advances by BK rows per step and whose num_records shrinks to the rows left
     //   in this pixel slice: lane offsets are constants and rows beyond the slice read zeros - no per-step VALU at all.
     // B (gathered x): when the BK pixels of a K step lie in ONE image (H * W % BK == 0, no on-the-fly upsample) pixel `row` of
     //   the step sits at (oy0 + (row >> logW), ox0 + (row & (W - 1))) with (oy0, ox0) wave-uniform, so the element offset is
     //   U(n, oy0, ox0)  [SALU]  +  L(tap, channel, tile row)  [lane constant]; only the zero-padding test is per lane (two adds,
     //   two compares, one select per tile row).  Otherwise (1x1 and 2x2 maps) the generic per-row address path runs.
-    constexpr bool fastb = FASTB;  // host: VEC == 4 && ups == 0 && H * W % BK == 0
+    constexpr bool fastb = FASTB;  // host: VB == 4 && ups == 0 && H * W % BK == 0
     unsigned a_v[A_PER], b_l[B_PER];
     int b_dx[B_PER], b_dy[B_PER];
     // the most negative lane constant is shifted into the base pointer so that every offset is a non-negative 32-bit value
     const int b_bias = ((g.off_y < 0 ? -g.off_y : 0) * g.Win + (g.off_x < 0 ? -g.off_x : 0)) * p.Cin * 4;
     const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - b_bias), 0, p.x_bytes + (unsigned)b_bias, 0x00020000);
-    if constexpr (VEC == 4) {
+    if constexpr (VA == 4) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int row = ak + i * A_RSTEP;
             a_v[i] = row < BK ? (unsigned)((row * p.Cout + min(co0 + ac, p.Cout - 4)) * 4) : BUF_OOB;
         }
+    }
+    if constexpr (VB == 4) {
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int row = bk + i * B_RSTEP;
@@ -820,15 +824,15 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
 
     // staging registers; bf16x3: two sets, loads run two K steps ahead of their LDS store (as in conv_igemm_kernel)
     constexpr int NSET = X3 ? 2 : 1;
-    float raS[NSET][A_PER][VEC], rbS[NSET][B_PER][VEC];
-    float bsum[VEC];
+    float raS[NSET][A_PER][VA], rbS[NSET][B_PER][VB];
+    float bsum[VA];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) bsum[e] = 0.f;
+    for (int e = 0; e < VA; ++e) bsum[e] = 0.f;
 
     auto load_tiles = [&](int mb, auto SETC) {
         auto& ra = raS[decltype(SETC)::value];
         auto& rb = rbS[decltype(SETC)::value];
-        if constexpr (VEC == 4) {
+        if constexpr (VA == 4) {
             const int left = mend - mb;  // > 0
             const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(p.dy + (long long)mb * p.Cout), 0, (unsigned)min(left, BK) * (unsigned)p.Cout * 4u, 0x00020000);
@@ -838,6 +842,16 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ra[i][e] = val[e];
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int row = ak + i * A_RSTEP;
+                const int m = mb + row;
+                const bool v = a_cok && row < BK && m < mend;
+                ra[i][0] = v ? p.dy[(long long)m * p.Cout + co0 + ac] : 0.f;
+            }
+        }
+        if constexpr (VB == 4) {
             if constexpr (fastb) {
                 const int n = mb >> (g.logH + g.logW);
                 const int oys = ((mb >> g.logW) & (g.H - 1)) * g.s_in, oxs = (mb & (g.W - 1)) * g.s_in;
@@ -866,13 +880,6 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int row = ak + i * A_RSTEP;
-                const int m = mb + row;
-                const bool v = a_cok && row < BK && m < mend;
-                ra[i][0] = v ? p.dy[(long long)m * p.Cout + co0 + ac] : 0.f;
-            }
-#pragma unroll
             for (int i = 0; i < B_PER; ++i) {
                 const int row = bk + i * B_RSTEP;
                 const int m = mb + row;
@@ -894,19 +901,19 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.a_slope, p.pos_inf);
+                for (int e = 0; e < VA; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.a_slope, p.pos_inf);
         }
         if (do_bias) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) bsum[e] += ra[i][e];
+                for (int e = 0; e < VA; ++e) bsum[e] += ra[i][e];
         }
         if (act_b) {
 #pragma unroll
             for (int i = 0; i < B_PER; ++i)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) rb[i][e] = __builtin_amdgcn_fmed3f(rb[i][e], rb[i][e] * p.pre_slope, p.pos_inf);
+                for (int e = 0; e < VB; ++e) rb[i][e] = __builtin_amdgcn_fmed3f(rb[i][e], rb[i][e] * p.pre_slope, p.pos_inf);
         }
         if constexpr (X3) {
 #pragma unroll
@@ -925,7 +932,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         for (int i = 0; i < A_PER; ++i) {
             const int row = ak + i * A_RSTEP;
             if (row < BK) {
-                if constexpr (VEC == 4) {
+                if constexpr (VA == 4) {
                     f32x4 val = {ra[i][0], ra[i][1], ra[i][2], ra[i][3]};
                     *reinterpret_cast<f32x4*>(&As[buf][row * BM + ac]) = val;
                 } else {
@@ -937,7 +944,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         for (int i = 0; i < B_PER; ++i) {
             const int row = bk + i * B_RSTEP;
             if (row < BK) {
-                if constexpr (VEC == 4) {
+                if constexpr (VB == 4) {
                     f32x4 val = {rb[i][0], rb[i][1], rb[i][2], rb[i][3]};
                     *reinterpret_cast<f32x4*>(&Bs[buf][row * BN + bc]) = val;
                 } else {
@@ -1073,9 +1080,9 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         }
 
     if (do_bias) {  // block-uniform; As is free after the loop's last barrier
-        float* red = &As[0][0];  // needs (256 / AU) * BM = 256 * VEC <= 2 * BK * BM floats
+        float* red = &As[0][0];  // needs (256 / AU) * BM = 256 * VA <= 2 * BK * BM floats
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) red[ak * BM + ac + e] = bsum[e];
+        for (int e = 0; e < VA; ++e) red[ak * BM + ac + e] = bsum[e];
         __syncthreads();
         if (t < BM && co0 + t < p.Cout) {
             float sacc = 0.f;
@@ -1432,24 +1439,39 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     q.cols = KF * KF * (up_fold ? s->Cout : s->Cin);
     const long long M = (long long)s->N * (s->H >> (s->wfold ? 1 : 0)) * (s->W >> (s->wfold ? 1 : 0));
     q.M = (int)M;
-    q.bm = q.rows > 64 ? 128 : (q.rows > 32 ? 64 : 32);
-    q.bn = (q.bm == 32) ? 128 : (q.cols > 64 ? 128 : 64);
-    const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
-    // about two workgroups per CU in total, and at least 32 K-steps (512 pixels) per workgroup so that the
-    // slab write + later slab reduction stay small next to the MFMA work
+    // launch choice: the caller's (gim_conv_shape.tune_tile / tune_wgrad), else the table row of this shape, else the heuristic
     int target = s->tune_wgrad > 0 ? s->tune_wgrad : 0;
-    if (!target && s->tune_tile < 0) target = 1024;   // heuristics only
-    if (!target) {
+    int tile = s->tune_tile > 0 ? s->tune_tile : 0;
+    if (!target && !tile && s->tune_tile == 0) {
         const int pcw = (s->pool ? 1 : 0) + (up_fold ? 2 : 0);
         const TuneEntry* te = s->prec == 1 ? tune_lookup(5, (int)M, q.rows, q.cols, s->KH, pcw) : nullptr;   // bf16x3 rows first
         if (!te) te = tune_lookup(2, (int)M, q.rows, q.cols, s->KH, pcw);
-        target = te ? te->ks : 1024;
-        q.table_hit = te ? 1 : 0;
+        if (te) { target = te->ks; tile = te->tile; q.table_hit = 1; }
+    }
+    q.bm = q.rows > 64 ? 128 : (q.rows > 32 ? 64 : 32);
+    q.bn = (q.bm == 32) ? 128 : (q.cols > 64 ? 128 : 64);
+    if (tile == 128) { q.bm = 128; q.bn = 128; }
+    else if (tile == 641) { q.bm = 64; q.bn = 128; }
+    else if (tile == 1264) { q.bm = 128; q.bn = 64; }
+    else if (tile == 64) { q.bm = 64; q.bn = 64; }
+    else if (tile == 32128) { q.bm = 32; q.bn = 128; }
+    const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
+    // Heuristic: about four workgroups per CU in total and at least 32 K-steps (512 pixels) per workgroup, so that the float
+    // atomics of the combine stay small next to the MFMA work - unless that leaves most CUs idle (1x1 convs and linears on small
+    // maps: few tiles, few pixels): a launch with one workgroup per CU runs one wave per SIMD and pays the full load latency every
+    // K step (~1.8 us), so short slices on many CUs win although they add more partial tiles (measured: tools/conv_autotune.py).
+    // An explicit / table target lifts the 512-pixel floor to 64 (4 K-steps).
+    long long minpix = 512;
+    if (!target) {
+        target = 1024;
+        if (tiles * ((M + 511) / 512) < 256) minpix = 128;
+    } else {
+        minpix = 64;
     }
     long long S = (target + tiles - 1) / tiles;
-    const long long maxS = (M + 511) / 512;
+    const long long maxS = (M + minpix - 1) / minpix;
     if (S > maxS) S = maxS;
-    if (S > 256) S = 256;
+    if (S > 1024) S = 1024;
     if (S < 1) S = 1;
     long long mp = (M + S - 1) / S;
     mp = (mp + BK - 1) / BK * BK;
@@ -1469,20 +1491,20 @@ extern "C" int gim_conv2d_wgrad_slabs(const gim_conv_shape* s) {
 
 template <bool FASTB>
 static void launch_wgrad_x3(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
 }
 
-template <int VEC, bool FASTB>
+template <int VA, int VB, bool FASTB>
 static void launch_wgrad(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, VEC, FASTB>), g, dim3(256), 0, st, p);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, VEC, FASTB>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, VEC, FASTB>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, VEC, FASTB>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, VEC, FASTB>), g, dim3(256), 0, st, p);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, VA, VB, FASTB>), g, dim3(256), 0, st, p);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, VA, VB, FASTB>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, VA, VB, FASTB>), g, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, VA, VB, FASTB>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, VA, VB, FASTB>), g, dim3(256), 0, st, p);
 }
 
 // prezeroed: the caller guarantees slabs / bias_slabs hold zeros (or a partial sum to add to): pixel slices are combined
@@ -1526,15 +1548,20 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
         for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
         return GIM_OK;
     }
-    const bool vec = (s->Cin % 4 == 0) && (s->Cout % 4 == 0) && !(((uintptr_t)dy | (uintptr_t)x) & 15);
-    const bool fastb = vec && p.g.ups == 0 && ((p.g.H * p.g.W) & (BK - 1)) == 0;   // a K step stays inside one image
-    if (s->prec == 1 && vec) {
-        if (fastb) launch_wgrad_x3<true>(p, q.bm, q.bn, g, (hipStream_t)stream);
-        else launch_wgrad_x3<false>(p, q.bm, q.bn, g, (hipStream_t)stream);
+    // per operand as the kernel sees it (the sub-pixel form swaps the roles): A = p.dy with p.Cout channels, B = p.x with p.Cin
+    const bool va = (p.Cout % 4 == 0) && !((uintptr_t)p.dy & 15);
+    const bool vb = (p.Cin % 4 == 0) && !((uintptr_t)p.x & 15);
+    const bool fastb = vb && p.g.ups == 0 && ((p.g.H * p.g.W) & (BK - 1)) == 0;   // a K step stays inside one image
+    hipStream_t st = (hipStream_t)stream;
+    if (s->prec == 1 && va && vb) {
+        if (fastb) launch_wgrad_x3<true>(p, q.bm, q.bn, g, st);
+        else launch_wgrad_x3<false>(p, q.bm, q.bn, g, st);
     }
-    else if (fastb) launch_wgrad<4, true>(p, q.bm, q.bn, g, (hipStream_t)stream);
-    else if (vec) launch_wgrad<4, false>(p, q.bm, q.bn, g, (hipStream_t)stream);
-    else launch_wgrad<1, false>(p, q.bm, q.bn, g, (hipStream_t)stream);
+    else if (va && fastb) launch_wgrad<4, 4, true>(p, q.bm, q.bn, g, st);
+    else if (va && vb) launch_wgrad<4, 4, false>(p, q.bm, q.bn, g, st);
+    else if (va) launch_wgrad<4, 1, false>(p, q.bm, q.bn, g, st);
+    else if (vb) launch_wgrad<1, 4, false>(p, q.bm, q.bn, g, st);
+    else launch_wgrad<1, 1, false>(p, q.bm, q.bn, g, st);
     return gim_check_launch("gim_conv2d_wgrad");
 }
 

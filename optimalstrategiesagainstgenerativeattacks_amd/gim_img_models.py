@@ -24,9 +24,17 @@ _STREAMS = {}
 
 
 def _use_side_streams(t):
-    """Lane 1 forks side streams of its own (a fork of a fork).  hipStreamEndCapture of ROCm 7.2 segfaults on that
-    shape of graph (tools/capture_probe.py), so graph capture uses the sequential protocol, lane 0 only (graph.py)."""
-    return _TWO_STREAMS and t.is_cuda and (ops.current_lane() == 0 or _LANE1_SIDE)
+    """Side streams for this call?  Lane 1 forks side streams of its own - a fork of a fork.  Under hipGraph capture that shape
+    is avoided: on ROCm 7.2 a captured stream that waits for an event recorded on ANOTHER FORKED stream (anything but the
+    capture's origin stream) takes the process down with a segmentation fault - plain torch, nothing of this package involved:
+    tools/capture_probe.py cases t_fork2 / t_selfwait / t_alias crash, t_fork (one level: fork from the origin, join into the
+    origin) captures and replays, t_unjoined is refused with hipErrorStreamCaptureUnjoined as it should be.  So while capturing,
+    lane 1 keeps to its own stream (one level below the origin), and lane 0's side streams fork from / join into the origin."""
+    if not (_TWO_STREAMS and t.is_cuda):
+        return False
+    if ops.current_lane() == 0:
+        return True
+    return _LANE1_SIDE and not torch.cuda.is_current_stream_capturing()
 
 
 # Role -> stream map.  Roles: 0, 1 = lane 0's two side streams, 2 = lane 1's main stream, 3, 4 = lane 1's side streams

@@ -12,10 +12,17 @@ Product-independent cases (plain torch ops, nothing of this repo is imported):
 Product cases (the tiny config): op | zero | adam | fwd | fwdg | bwd | full on lane 1's stream forked from the capture stream,
     gimstep       GraphedGimStep(overlap=True): the whole two-lane iteration captured, replayed, compared with eager
 """
+import faulthandler
 import os
 import sys
 
 import torch
+
+faulthandler.enable()
+
+
+def mark(msg):
+    print("  [%s] %s" % (sys.argv[1], msg), flush=True)
 
 case = sys.argv[1]
 dev = torch.device("cuda:0")
@@ -33,15 +40,22 @@ def torch_only():
         with torch.cuda.stream(A):
             y = x * 2
             if case == "t_fork2":
+                mark("B.wait_stream(A): event recorded on forked A, waited for by B")
                 B.wait_stream(A)
+                mark("... returned")
                 with torch.cuda.stream(B):
                     z = y + 1
                 A.wait_stream(B)
                 y = z * 3
             elif case == "t_selfwait":
+                mark("A.wait_stream(A): event recorded on forked A, waited for by A")
                 A.wait_stream(A)
+                mark("... returned")
                 y = y + 5
                 A.wait_stream(A)
+            elif case == "t_originwait":        # a forked stream waits twice for events of the ORIGIN: must be fine
+                A.wait_stream(cur)
+                y = y + 5
             elif case == "t_alias":
                 B.wait_stream(cur)          # B forked from the origin ...
                 with torch.cuda.stream(B):
@@ -64,6 +78,7 @@ def torch_only():
     try:
         with torch.cuda.graph(g, stream=C):
             body()
+            mark("body captured; leaving the capture (hipStreamEndCapture)")
     except RuntimeError as e:
         print("case %s: capture raised (no crash): %s" % (case, str(e).splitlines()[0][:150]))
         return

@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--append", action="store_true", help="keep the entries already in the table (other workloads)")
     ap.add_argument("--min-gain", type=float, default=0.03)
+    ap.add_argument("--kinds", default="fwd,dgrad,wgrad", help="which kernel kinds to tune (comma separated)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     fwd, bwd = record_shapes(args.workload, args.batch)
@@ -71,8 +72,7 @@ def main():
     tot_auto = tot_best = 0.0
     for cfg, cnt in sorted(fwd.items(), key=lambda kv: -kv[1]):
         N, H, W, Cin, Cout, KH, ups, slope, pool, fold = cfg
-        if Cin % 16 or Cout % 16:
-            continue   # generic-K layers (3 / 6 channels): heuristics only
+        narrow = bool(Cin % 16 or Cout % 16)   # generic-K layers (3 / 6 channels): forward / dgrad use the heuristics, wgrad is tuned
         n_dx = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dx)
         n_dw = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dw)
         x3 = ops.conv_precision() == 1      # bf16x3 matrix path: its own table rows (kinds 3, 4, 5)
@@ -117,13 +117,13 @@ def main():
                 "dgrad": (n_dx, dgrad_fn),
                 "wgrad": (n_dw, lambda sh_: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh_, st))}
         for kind, (calls, fn) in runs.items():
-            if not calls or (x3 and keys[kind][0] < 3):   # bf16x3 pass: only its own rows (kinds 3, 4, 5)
+            if not calls or (x3 and keys[kind][0] < 3) or kind not in args.kinds.split(",") or (narrow and kind != "wgrad"):   # bf16x3 pass: only its own rows (kinds 3, 4, 5)
                 continue
             Cb = keys[kind][3]
             t_auto = time_ms(lambda: fn(sh))
             best = (t_auto, 0, 0)
-            if kind == "wgrad":
-                cands = [(0, 0, tg) for tg in (256, 512, 2048, 4096)]
+            if kind == "wgrad":   # output tile x workgroup target of the pixel slicing (an explicit target lifts the 512-pixel floor)
+                cands = [(tl, 0, tg) for tl in (0, 128, 641, 1264, 64) for tg in (128, 256, 512, 1024, 2048, 4096, 8192)]
             else:
                 tiles = [128, 641, 1264, 64] if Cb > 64 else ([1264, 64] if Cb > 32 else [])
                 cands = [(tl, ks, 0) for tl in tiles for ks in (1, 2, 3, 4, 6, 8)]
