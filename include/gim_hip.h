@@ -56,13 +56,17 @@ int gim_version(void);
  *             (the product's value) = the table row of this shape, else the heuristic.  tune_tile: 128 = 128x128, 641 =
  *             64x128, 1264 = 128x64, 64 = 64x64 output tile, < 0 = ignore the table; tune_ksplit: split-K factor of
  *             fwd / dgrad; tune_wgrad: workgroup target of the wgrad pixel slicing.  Results never depend on them beyond
- *             the summation order. */
+ *             the summation order.
+ *   out_zeroed = 1: (gim_conv2d_fwd / _dgrad / _dgrad_t) the caller guarantees that the output buffer holds zeros.  Launches that
+ *             split K over the grid combine their slices with float atomics and otherwise clear the output themselves (one
+ *             memset per launch); a caller that hands out outputs from a zero-filled pool saves those launches. */
 typedef struct {
     int32_t N, H, W, Cin, Cout, KH, ups;
     float pre_slope;
     int32_t pool, wfold, res_ups;
     int32_t prec;
     int32_t tune_tile, tune_ksplit, tune_wgrad;
+    int32_t out_zeroed;
 } gim_conv_shape;
 
 /* F[co][a][b][ci] = sum_{dh,dw in {0,1}} w[co][a-dh][b-dw][ci], a, b in [0, KH]  (out-of-range taps are zero). */

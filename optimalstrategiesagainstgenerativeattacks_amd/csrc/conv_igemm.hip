@@ -1348,7 +1348,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
     p.prec = s->prec;
     p.tune_kind = s->prec == 1 ? 3 : 0;
-    p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit;
+    p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit; p.y_zeroed = s->out_zeroed;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
@@ -1398,7 +1398,7 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
     const bool bscalar = (s->Cin % 4) != 0 || ((uintptr_t)w & 15);
     hipStream_t st = (hipStream_t)stream;
     p.tune_kind = 1;
-    p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit;
+    p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit; p.y_zeroed = s->out_zeroed;
     if (transposed) {
         // WT[ci][a][b][co]: the weight rows are k-contiguous (k = (tap, co)), i.e. the forward kernel's operand layout
         GIM_CHECK_ARG(!gen && !((uintptr_t)w & 15), "conv dgrad (transposed weights): Cout % 16 == 0 and 16-byte aligned operands required");

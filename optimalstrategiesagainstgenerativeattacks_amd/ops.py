@@ -140,7 +140,56 @@ def set_conv_precision(mode):
 
 
 def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
-    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, _CONV_PREC[0], 0, 0, 0)
+    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, _CONV_PREC[0], 0, 0, 0, 0)
+
+
+# Outputs of split-K launches.  A layer whose output tiles do not fill the chip is sliced along K over the grid and its slices
+# are combined with float atomics into a ZEROED output: ~250 such launches per training step, each with its own memset in front
+# (a 7 us fill kernel plus a kernel boundary).  Instead those outputs are carved out of pages that ONE torch.zeros call clears
+# (per stream, 16 MB at a time): views keep their page alive, so tensor lifetimes are the usual ones; whether a launch splits K
+# is asked from the library once per shape (gim_conv_launch_plan) and cached.
+_ZERO_POOL = os.environ.get("GIM_NO_ZERO_POOL") is None   # A/B switch (host side)
+_SPLITS_K = {}
+_ZERO_PAGES = {}
+_ZERO_PAGE = 4 << 20   # floats per page (16 MB)
+
+
+def _splits_k(sh, plan_kind, key):
+    """Does this launch combine K slices with atomics (and so need a zeroed output)?"""
+    k_ = (plan_kind, sh.prec) + key
+    v = _SPLITS_K.get(k_)
+    if v is None:
+        out = (ctypes.c_int32 * 8)()
+        check(_lib.load().gim_conv_launch_plan(ctypes.byref(sh), plan_kind, ctypes.cast(out, ctypes.c_void_p)), "conv_launch_plan")
+        v = _SPLITS_K[k_] = out[3] > 1
+    return v
+
+
+def _zeros_from_pool(shape, device):
+    """A zero-filled float32 tensor of `shape`, cleared together with its neighbours by one fill per 16 MB page (pages are per
+    stream: the fill and the kernels that use the page are in stream order)."""
+    n = 1
+    for d in shape:
+        n *= d
+    na = (n + 63) & ~63
+    if na > _ZERO_PAGE >> 2:     # a big output: its own fill (a view pins its whole page for as long as it lives)
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+    raw = _stream()
+    pg = _ZERO_PAGES.get(raw)
+    if pg is None or pg[1] + na > pg[0].numel():
+        pg = _ZERO_PAGES[raw] = [torch.zeros(_ZERO_PAGE, device=device, dtype=torch.float32), 0]
+    v = pg[0][pg[1]:pg[1] + n].view(shape)
+    pg[1] += na
+    return v
+
+
+def _conv_out(sh, plan_kind, key, shape, device):
+    """Output buffer of a forward (plan_kind 0) / dgrad (1, 2) launch: zeros from the pool when the launch splits K (and
+    sh.out_zeroed tells the library not to clear it again), plain torch.empty otherwise."""
+    if _ZERO_POOL and _splits_k(sh, plan_kind, key) and not torch.cuda.is_current_stream_capturing():
+        sh.out_zeroed = 1
+        return _zeros_from_pool(shape, device)
+    return torch.empty(shape, device=device, dtype=torch.float32)
 
 
 # --------------------------------------------------------------------------------------------
@@ -385,7 +434,7 @@ class ConvFn(Function):
         fold = 1 if (pool or (ups and KH > 1)) else 0
         sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
         Ho, Wo = (H >> 1, W >> 1) if pool else (H, W)
-        y = torch.empty((N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        y = _conv_out(sh, 0, (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold), (N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), x.device)
         if res is not None:
             res = _req(res, "res")
         if fold and wf is None:
@@ -438,6 +487,7 @@ class ConvFn(Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
+_NARROW_DGRAD_T = os.environ.get("GIM_NO_NARROW_DGRAD_T") is None   # A/B switch (host side)
 _WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
 
 
@@ -472,17 +522,23 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
     if _FLOPS is not None:
         _note_conv("dgrad", cfg)
     mask = x if pre_slope != 1.0 else None
-    dx = torch.empty_like(x)
+    key = (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold)
     wk = wf if fold else wp
-    if w is not None and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold) and sh.prec == 1:
+    # dgrad on cached transposed weights WT[Cin][KF][KF][Cout] (rows k-contiguous: the forward kernel's operand path, vector weight
+    # loads): on the bf16x3 path for the 16-multiple layers, and - on either path - for the gradient w.r.t. IMAGES (<= 8 input
+    # channels: 3 / 6 / 1), where the k-major kernel falls back to scalar weight loads (output channels not a multiple of 4)
+    if w is not None and Cout % 16 == 0 and not (ups and not fold) and ((sh.prec == 1 and Cin >= 32) or (Cin <= 8 and _NARROW_DGRAD_T)):
         wt = _transposed(lib, w, wk, Cout, Cin, KH + 1 if fold else KH)
+        dx = _conv_out(sh, 2, key, tuple(x.shape), x.device)
         check(lib.gim_conv2d_dgrad_t(_p(dy), _p(wt), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad_t")
         return dx
     if ups and not fold:
-        dxu = torch.empty((N, H, W, Cin), device=dy.device, dtype=torch.float32)
+        dxu = _conv_out(sh, 1, key, (N, H, W, Cin), dy.device)
+        dx = torch.empty_like(x)
         check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), None, _p(dxu), sh, st), "conv2d_dgrad")
         check(lib.gim_upsample2x_bwd(_p(dxu), _p(mask), pre_slope, _p(dx), N, H >> 1, W >> 1, Cin, st), "upsample2x_bwd")
     else:
+        dx = _conv_out(sh, 1, key, tuple(x.shape), x.device)
         check(lib.gim_conv2d_dgrad(_p(dy), _p(wk), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad")
     return dx
 
