@@ -370,6 +370,8 @@ def _assert_one_adam_step_matches_oracle(params, buffers, otr, lrs, beta2=0.99):
             lr = 1e-4 if kk.startswith("env_noise_mapper") and name == "im" else lrs[name]
             # ... and is well above Adam's eps = 1e-8 (g / (|g| + eps) is sensitive to the last bits of a gradient of that size)
             mask = (gabs > 1e-3 * rms) & (gabs > 1e-6)
+            if not bool(mask.any()):
+                continue
             diff = (p.detach().double().cpu() - sd_o[kk].detach()).abs()[mask]
             off = float((diff > 0.05 * lr).double().mean())
             assert off < 1e-3, (name, kk, "share of elements whose update differs from the oracle's", off, float(diff.max()))

@@ -79,7 +79,7 @@ def main():
         flops = ops.conv_executed_flops(N, H, W, Cin, Cout, KH, ups, pool, fold)      # what the kernels execute (folds!)
         algo = ops.conv_algorithmic_flops(N, H, W, Cin, Cout, KH)                      # the unfused reference op
         t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
-        if prec == 1 and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
+        if Cout % 16 == 0 and not (ups and not fold) and ((prec == 1 and Cin >= 32) or Cin <= 8):   # as ops._conv_dgrad
             wt = torch.empty(Cin * KF * KF * Cout, device=dev)
             lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
             t_d = time_ms(lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
