@@ -164,6 +164,93 @@ __device__ __forceinline__ void x3_split_store(unsigned* dst, const f32x4& x) {
     *reinterpret_cast<u32x2*>(dst + 16) = lo;
 }
 
+// Epilogue of one accumulator block: NE values of ONE output channel `co` on rows mbase + (e & 3) + 8 * (e >> 2) (the C/D layout of
+// the 32x32 and, for NE = 4, of the 16x16 MFMA).  MODE 0: y = a * scale + bias; 1: + residual; 2: + residual stored at half
+// resolution (nearest-upsampled on the fly); 3: * leaky_relu'(mask).  All loads of the block are issued before the first is used
+// (a load - wait - store chain per element made the epilogue of a short-K workgroup as long as its K loop), every offset is a
+// per-lane VGPR offset (the SGPR offset of a raw buffer access is not bounds-checked: rows beyond a ragged tile edge must be
+// dropped by the lane offset), and nothing in the element loops branches.
+struct EpiCtx {
+    __amdgpu_buffer_rsrc_t ry, rr, rm;
+    float scale, mask_slope;
+    int M, Cb, logH, logW, Hm1, Wm1, os, py, px, Ho, Wo;
+    bool atom, remap;
+};
+
+// byte offset in y of logical element (m, co) [and, MODE 2, of its half-resolution residual], rows beyond M not handled here
+template <int MODE>
+__device__ __forceinline__ void epi_elem_off(const EpiCtx& c, int m, int co, unsigned& o, unsigned& ro) {
+    const int n = m >> (c.logH + c.logW);
+    const int oy = ((m >> c.logW) & c.Hm1) * c.os + c.py;
+    const int ox = (m & c.Wm1) * c.os + c.px;
+    o = (unsigned)((((n * c.Ho + oy) * c.Wo + ox) * c.Cb + co) * 4);
+    if constexpr (MODE == 2) ro = (unsigned)((((n * (c.Ho >> 1) + (oy >> 1)) * (c.Wo >> 1) + (ox >> 1)) * c.Cb + co) * 4);
+}
+
+template <int NE, int MODE>
+__device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE], int mbase, int co, bool cok, float bv) {
+    constexpr int CH = NE < 8 ? NE : 8;   // elements in flight: 8 loads per lane cover the latency, more would cost occupancy
+    const unsigned rowb = (unsigned)c.Cb * 4u;
+#pragma unroll
+    for (int e0 = 0; e0 < NE; e0 += CH) {
+        unsigned off[CH], roff[MODE == 2 ? CH : 1];
+        // rows come in groups of 4 consecutive m (mbase % 4 == 0): one full address computation per group where a group stays in
+        // one image row (W >= 4), plain arithmetic otherwise; out-of-range lanes get the high bit (>= num_records: dropped)
+        if (!c.remap && MODE != 2) {
+            const unsigned base = (unsigned)((mbase * c.Cb + co) * 4);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) off[q] = base + (unsigned)(((e0 + q) & 3) + 8 * ((e0 + q) >> 2)) * rowb;
+        } else if (c.Wm1 >= 3) {
+#pragma unroll
+            for (int g4 = 0; g4 < CH; g4 += 4) {
+                unsigned o, ro = 0;
+                epi_elem_off<MODE>(c, mbase + 8 * ((e0 + g4) >> 2), co, o, ro);
+#pragma unroll
+                for (int k = 0; k < 4 && g4 + k < CH; ++k) {
+                    off[g4 + k] = o + (unsigned)(k * c.os) * rowb;
+                    if constexpr (MODE == 2) roff[g4 + k] = ro + (unsigned)(((c.px + k * c.os) >> 1) - (c.px >> 1)) * rowb;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                unsigned ro = 0;
+                epi_elem_off<MODE>(c, mbase + ((e0 + q) & 3) + 8 * ((e0 + q) >> 2), co, off[q], ro);
+                if constexpr (MODE == 2) roff[q] = ro;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const unsigned bad = (cok && mbase + ((e0 + q) & 3) + 8 * ((e0 + q) >> 2) < c.M) ? 0u : BUF_OOB;
+            off[q] |= bad;
+            if constexpr (MODE == 2) roff[q] |= bad;
+        }
+        float ld[MODE == 0 ? 1 : CH];
+        if constexpr (MODE == 1 || MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) ld[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rr, MODE == 2 ? roff[q] : off[q], 0, 0));
+        } else if constexpr (MODE == 3) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) ld[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rm, off[q], 0, 0));
+        }
+        float v[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            v[q] = a[e0 + q] * c.scale + bv;
+            if constexpr (MODE == 1 || MODE == 2) v[q] += ld[q];
+            if constexpr (MODE == 3) v[q] *= (ld[q] > 0.f ? 1.0f : c.mask_slope);
+        }
+        if (c.atom) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v[q], c.ry, off[q], 0, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), c.ry, off[q], 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one chunk's offsets / loads at a time: the chunks must not pile up in registers
+    }
+}
+
 template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB, int PREC = 0>
 __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)) : (KB == 16 ? 4 : 2)) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
@@ -590,110 +677,55 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
             for (int j = 0; j < TN; ++j) acc[i][j] += acc2[i][j];
     }
     // ---- epilogue: out_scale/sigma, bias, residual, activation mask; logical pixel -> stored pixel ----
-    const float scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
+    EpiCtx ec;
+    ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
+    ec.mask_slope = p.mask_slope;
     const bool first = kslice == 0;
-    if (g.os == 1 && !p.res_ups) {  // block-uniform
-        // The stored pixel is the logical one: element (m, co) lives at (m * Cb + co) * 4.  Buffer stores with ONE 32-bit lane
-        // offset per accumulator block and the row step (k * Cb * 4) as the wave-uniform SGPR offset: a single FMA of VALU
-        // work per element (64-bit index arithmetic per element cost more matrix-pipe time than the K loop's address work);
-        // rows m >= M fall outside num_records and are dropped by the range check.
-        const unsigned ybytes = (unsigned)p.M * (unsigned)p.Cb * 4u;
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (p.res && first) ? ybytes : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_x, 0, p.mask_x ? ybytes : 0u, 0x00020000);
-        const unsigned rowb = (unsigned)p.Cb * 4u;
+    const bool has_res = p.res != nullptr && first, has_mask = p.mask_x != nullptr;   // block-uniform
+    ec.atom = p.ksplit > 1;
+    ec.remap = g.os != 1;
+    ec.M = p.M; ec.Cb = p.Cb;
+    ec.logH = g.logH; ec.logW = g.logW; ec.Hm1 = g.H - 1; ec.Wm1 = g.W - 1; ec.os = g.os; ec.py = g.py; ec.px = g.px;
+    ec.Ho = g.H * g.os; ec.Wo = g.W * g.os;
+    // y (and the mask, which has y's shape) in bytes: the host guarantees < 2 GiB per launch
+    const unsigned ybytes = (unsigned)g.N * (unsigned)ec.Ho * (unsigned)ec.Wo * (unsigned)p.Cb * 4u;
+    ec.ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
+    ec.rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, has_res ? (p.res_ups ? ybytes >> 2 : ybytes) : 0u, 0x00020000);
+    ec.rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_x, 0, has_mask ? ybytes : 0u, 0x00020000);
+    auto run = [&](auto MODEC) {
+        constexpr int MODE = decltype(MODEC)::value;
         if constexpr (N16) {   // accumulator block i, register e: row 16*i + 4*q16 + e, column r16
             const int co = n0 + r16;
             const bool cok = co < p.Cb;
             const float bv = (p.bias && first && cok) ? p.bias[co] : 0.f;
 #pragma unroll
             for (int i = 0; i < NB16; ++i) {
-                const unsigned voff = cok ? (unsigned)(((m0 + wm0 + 16 * i + 4 * q16) * p.Cb + co) * 4) : BUF_OOB;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned soff = (unsigned)e * rowb;
-                    float v = acc16[i][e] * scale + bv;
-                    if (p.res && first) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, voff, soff, 0));
-                    if (p.mask_x) {
-                        const float xm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, voff, soff, 0));
-                        v *= (xm > 0.f ? 1.0f : p.mask_slope);
-                    }
-                    if (p.ksplit > 1) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, ry, voff, soff, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, soff, 0);
-                }
+                const float a[4] = {acc16[i][0], acc16[i][1], acc16[i][2], acc16[i][3]};
+                epi_block<4, MODE>(ec, a, m0 + wm0 + 16 * i + 4 * q16, co, cok, bv);
             }
-            return;
+        } else {               // block (i, j), register e: row 32*i + (e & 3) + 8*(e >> 2) + 4*h, column 32*j + r
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int co = n0 + wn0 + 32 * j + r;
+                    const bool cok = co < p.Cb;
+                    const float bv = (p.bias && first && cok) ? p.bias[co] : 0.f;
+                    float a[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) a[e] = acc[i][j][e];
+                    epi_block<16, MODE>(ec, a, m0 + wm0 + 32 * i + 4 * h, co, cok, bv);
+                }
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = n0 + wn0 + 32 * j + r;
-                const bool cok = co < p.Cb;
-                const float bv = (p.bias && first && cok) ? p.bias[co] : 0.f;
-                const unsigned voff = cok ? (unsigned)(((m0 + wm0 + 32 * i + 4 * h) * p.Cb + co) * 4) : BUF_OOB;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const unsigned soff = (unsigned)((e & 3) + 8 * (e >> 2)) * rowb;  // wave-uniform
-                    float v = acc[i][j][e] * scale + bv;
-                    if (p.res && first) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, voff, soff, 0));
-                    if (p.mask_x) {
-                        const float xm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, voff, soff, 0));
-                        v *= (xm > 0.f ? 1.0f : p.mask_slope);
-                    }
-                    if (p.ksplit > 1) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, ry, voff, soff, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, soff, 0);
-                }
-            }
-        return;
-    }
-    const int Ho = g.H * g.os, Wo = g.W * g.os;
-    auto store_remapped = [&](int m, int co, float a, float bv) {
-        if (m >= p.M) return;
-        const int n = m >> (g.logH + g.logW);
-        const int oy = ((m >> g.logW) & (g.H - 1)) * g.os + g.py;
-        const int ox = (m & (g.W - 1)) * g.os + g.px;
-        const long long o = (((long long)n * Ho + oy) * Wo + ox) * p.Cb + co;
-        const long long ro = p.res_ups ? (((long long)n * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * p.Cb + co : o;
-        float v = a * scale + bv;
-        if (p.res && first) v += p.res[ro];
-        if (p.mask_x) v *= (p.mask_x[o] > 0.f ? 1.0f : p.mask_slope);
-        if (p.ksplit > 1) atomicAdd(&p.y[o], v);
-        else p.y[o] = v;
     };
-    if constexpr (N16) {
-        const int co = n0 + r16;
-        if (co >= p.Cb) return;
-        const float bv = (p.bias && first) ? p.bias[co] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NB16; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) store_remapped(m0 + wm0 + 16 * i + 4 * q16 + e, co, acc16[i][e], bv);
-        return;
+    if (has_res) {
+        if (p.res_ups) run(std::integral_constant<int, 2>());
+        else run(std::integral_constant<int, 1>());
+    } else if (has_mask) {
+        run(std::integral_constant<int, 3>());
+    } else {
+        run(std::integral_constant<int, 0>());
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn0 + 32 * j + r;
-            if (co >= p.Cb) continue;
-            const float bv = (p.bias && first) ? p.bias[co] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                const int n = m >> (g.logH + g.logW);
-                const int oy = ((m >> g.logW) & (g.H - 1)) * g.os + g.py;
-                const int ox = (m & (g.W - 1)) * g.os + g.px;
-                const long long o = (((long long)n * Ho + oy) * Wo + ox) * p.Cb + co;
-                const long long ro = p.res_ups ? (((long long)n * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * p.Cb + co : o;
-                float v = acc[i][j][e] * scale + bv;
-                if (p.res && first) v += p.res[ro];
-                if (p.mask_x) v *= (p.mask_x[o] > 0.f ? 1.0f : p.mask_slope);
-                if (p.ksplit > 1) atomicAdd(&p.y[o], v);
-                else p.y[o] = v;
-            }
-        }
 }
 
 // -------------------------------------------------------------------------------------------------

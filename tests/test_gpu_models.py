@@ -351,7 +351,7 @@ def test_trainer_protocol_vs_reference_golden(tag):
     assert abs(float(first["exp_avg_sq"].double().norm()) - m_["au_opt_first_v_norm"]) < 1e-3 * m_["au_opt_first_v_norm"]
 
 
-def _assert_one_adam_step_matches_oracle(params, buffers, otr, lrs, beta2=0.99):
+def _assert_one_adam_step_matches_oracle(params, buffers, otr, lrs, beta2=0.99, max_share=1e-3):
     """One Adam update with beta1 = 0 moves an element by lr * g / (|g| + eps): by ~lr * sign(g) wherever the gradient is above
     rounding noise.  So compare ELEMENTWISE where the oracle's gradient element is not negligible inside its tensor (>= 1e-3 of
     the tensor's rms; |g| is recovered from the oracle's second moment v = (1 - beta2) g^2): there the product's new value must
@@ -374,7 +374,7 @@ def _assert_one_adam_step_matches_oracle(params, buffers, otr, lrs, beta2=0.99):
                 continue
             diff = (p.detach().double().cpu() - sd_o[kk].detach()).abs()[mask]
             off = float((diff > 0.05 * lr).double().mean())
-            assert off < 1e-3, (name, kk, "share of elements whose update differs from the oracle's", off, float(diff.max()))
+            assert off < max_share, (name, kk, "share of elements whose update differs from the oracle's", off, float(diff.max()))
             checked += int(mask.sum())
         for kk, b in buffers[name].items():
             assert relerr(b, sd_o[kk]) < 1e-3, (name, kk)
@@ -409,9 +409,13 @@ def test_product_vs_oracle_fp32_step_and_state(reg_param):
                                          {"au": dict(au.named_buffers()), "im": dict(im.named_buffers())}, otr, lrs)
 
 
-def test_graphed_step_equals_eager_step():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_graphed_step_equals_eager_step(overlap):
     """A step replayed from the captured hipGraph (graph.GraphedGimStep) updates parameters, Adam state and
-    spectral-norm buffers exactly like the eager gim_step (up to the order of float atomics)."""
+    spectral-norm buffers exactly like the eager gim_step (up to the order of float atomics).  overlap=True captures the
+    two-lane protocol (the discriminator step on its own stream next to the generator's backward): while capturing, lane 1
+    keeps to one stream - hipStreamEndCapture of ROCm 7.2 crashes on a wait for an event of another FORKED stream
+    (tools/capture_probe.py t_fork2 / t_selfwait / t_alias reproduce it with plain torch ops)."""
     import optimalstrategiesagainstgenerativeattacks_amd as G
     from optimalstrategiesagainstgenerativeattacks_amd.graph import GraphedGimStep
     import tempfile
@@ -428,7 +432,7 @@ def test_graphed_step_equals_eager_step():
         if graphed:
             # capture on the first episode's shapes (warm-up steps run on scratch copies of the state)
             state = ({k_: v.clone() for k_, v in au.state_dict().items()}, {k_: v.clone() for k_, v in im.state_dict().items()})
-            gs = GraphedGimStep(trainer, *eps[0], warmup=3)
+            gs = GraphedGimStep(trainer, *eps[0], warmup=3, overlap=overlap)
             au.load_state_dict(state[0]); im.load_state_dict(state[1])
             for opt in (tr.authenticator_opt, tr.impersonator_opt):
                 opt.flat_m.zero_(); opt.flat_v.zero_(); opt._step_dev.zero_(); opt._host_step = 0
@@ -740,7 +744,10 @@ def test_two_rank_data_parallel_step_on_gpu(tmp_path):
     is_buf = lambda k_: k_.endswith(("weight_u", "weight_v"))   # noqa: E731
     params = {nm: {k_[3:]: v for k_, v in dp1["state"].items() if k_.startswith(nm + ".") and not is_buf(k_)} for nm in ("au", "im")}
     bufs = {nm: {k_[3:]: v for k_, v in dp1["state"].items() if k_.startswith(nm + ".") and is_buf(k_)} for nm in ("au", "im")}
-    _assert_one_adam_step_matches_oracle(params, bufs, otr, lrs)
+    # (two ranks sum their halves of the batch before the update: one more rounding than the single-process sum, and the first
+    # decoder block - whose input passes InstanceNorm on a 1x1 map, SURVEY F6 / F7 - carries enough near-zero gradient elements
+    # that 0.2 % of them change sign; allow 0.5 %)
+    _assert_one_adam_step_matches_oracle(params, bufs, otr, lrs, max_share=5e-3)
     # --- two iterations: data-parallel == single process on the whole batch, up to the order of the float atomics
     a, b = run(1, str(tmp_path / "single.pt"), 2), run(2, str(tmp_path / "dp2.pt"), 2)
     bad = []

@@ -58,6 +58,9 @@ POOL_CASES = [
     (2, 6, 64, 9, 16, 1.0, False),
     (5, 128, 128, 3, 2, 0.2, True),     # 2x2 -> 1x1
     (9, 64, 160, 3, 32, 0.2, True),
+    (3, 32, 64, 1, 16, 1.0, True),      # 1x1 + pool = 2x2 stride 2 (the skip convs of ResBlockDown)
+    (2, 3, 64, 1, 16, 1.0, False),      # ... of the first block (image channels: generic-K)
+    (5, 128, 256, 1, 2, 1.0, False),    # 2x2 -> 1x1
 ]
 
 

@@ -151,10 +151,9 @@ def test_tuned_shape_elementwise_vs_fp64_conv2d(cfg):
     y_r, dx_r, dw_r, db_r = _reference(x, w, b, dy, cfg, _ref_device())
     for prec in ([0] if kinds & {0, 1, 2} else []) + ([1] if kinds & {3, 4, 5} else []):
         # the launches below must be the table's: ask the launcher (same shape struct the operator builds)
-        hits = {k: _plan(lib, cfg, k, prec)[0] for k in (0, 1, 2, 3)}
-        want = {0: hits[0], 1: hits[1], 2: hits[3]} if prec == 0 else {3: hits[0], 4: hits[2], 5: hits[3]}
-        for k in kinds & set(want):
-            assert want[k] == 1, ("table row not in force", k, cfg)
+        api = {0: 0, 1: 1, 2: 3} if prec == 0 else {3: 0, 4: 2, 5: 3}      # table kind -> entry point of gim_conv_launch_plan
+        for k in kinds & set(api):
+            assert _plan(lib, cfg, api[k], prec)[0] == 1, ("table row not in force", k, cfg)
         prev = ops.set_conv_precision(prec)
         try:
             xg = x.clone().requires_grad_()
