@@ -255,10 +255,11 @@ def custom_std(x):
 
 
 class ResBlockDown(nn.Module):
-    """models/model_blocks.py:486-514, with both average pools folded away (exact in real arithmetic): each
-    avgpool(conv(.)) is ONE stride-2 convolution with the 2x2-folded weights - (K+1)^2 taps at a quarter of the pixels: 4 taps
-    for the 1x1 skip (no separate pooling kernel, no pooled copy of x, forward or backward), 16 for a 3x3 - and the skip is the
-    epilogue residual of the right branch's last convolution."""
+    """models/model_blocks.py:486-514, with both average pools folded away (exact in real arithmetic):
+    avgpool(conv1x1(x)) = conv1x1(avgpool(x)) for the skip (the 1x1 conv runs on a quarter of the pixels; folding the pool INTO
+    it as a 2x2-tap stride-2 conv was measured in round 2 and costs more than the pooling kernel it removes: 4x the FLOPs of
+    the skip conv, profiles/r02_avgpool_fold_1x1.txt), and avgpool(conv_r2(.)) + skip is ONE stride-2 convolution with the
+    2x2-folded weights and the low-resolution skip as its epilogue residual."""
 
     def __init__(self, in_channel, out_channel, conv_size=3, padding_size=1):
         super().__init__()
@@ -267,7 +268,7 @@ class ResBlockDown(nn.Module):
         self.conv_r2 = SNConv2d(out_channel, out_channel, conv_size, padding=padding_size)
 
     def forward(self, x):
-        left = self.conv_l1(x, pool=True)
+        left = self.conv_l1(ops.avg_pool2(x))
         out = self.conv_r1(x, pre_slope=LRELU)
         return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True)
 
