@@ -1,24 +1,36 @@
 #!/bin/bash
 # End-of-iteration measurement set on the GPU box (one gpurun call):  tools/measure_round.sh <tag>
-#   bench (default, om32, vox64 B=64), rocprofv3 kernel stats of the default bench, HBM traffic PMC passes.
+#   full GPU suite, default bench (traffic + CPU baseline), other workloads, rocprofv3 kernel stats, per-layer table, PMC of the
+#   dominant conv kernels.  Everything lands in gpurun_out/measure_<tag>/.
 tag=$1
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/measure_$tag
 mkdir -p $out
 cd $R
-python bench.py > $out/bench_vox64_B16.log 2>&1 || exit 1
-python bench.py --workload om32 --no-cpu-baseline --no-kernel-bench > $out/bench_om32_B32.log 2>&1 || exit 1
-python bench.py --batch 64 --no-cpu-baseline --no-kernel-bench > $out/bench_vox64_B64.log 2>&1 || exit 1
-python bench.py --reg-param 10 --no-cpu-baseline --no-kernel-bench > $out/bench_vox64_B16_r1.log 2>&1 || exit 1
-python bench.py --graph --no-cpu-baseline --no-kernel-bench > $out/bench_vox64_B16_graph.log 2>&1 || exit 1
-python bench.py --workload vox128 --no-cpu-baseline --no-kernel-bench > $out/bench_vox128_B2.log 2>&1 || exit 1
-MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 GIM_FORCE_ALLREDUCE=1 python bench.py --no-cpu-baseline --no-kernel-bench > $out/bench_vox64_B16_rccl1rank.log 2>&1 || exit 1
-python tools/conv_shapes_bench.py > $out/conv_shapes_fp32.txt 2>&1 || exit 1
-GIM_CONV_PREC=1 python tools/conv_shapes_bench.py > $out/conv_shapes_bf16x3.txt 2>&1 || exit 1
-python tools/host_overhead.py > $out/host_overhead.txt 2>&1 || exit 1
+timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; rc=$?
+echo "pytest rc=$rc: $(grep -E 'passed|failed' $out/pytest_gpu.log | tail -1)"; grep -E "^FAILED|^ERROR" $out/pytest_gpu.log | head
+[ $rc -ge 124 ] && exit $rc
+timeout -k 10 600 python bench.py > $out/bench_vox64_B16.log 2> $out/bench_vox64_B16.err || exit 1
+echo "bench: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_vox64_B16.log | head -1) $(grep -o '"executed_frac": [0-9.]*' $out/bench_vox64_B16.log) $(grep -o '"bf16x3_path": {"value": [0-9.]*' $out/bench_vox64_B16.log)"
+Q="--no-cpu-baseline --no-kernel-bench --no-traffic"
+timeout -k 10 300 python bench.py --workload om32 $Q > $out/bench_om32_B32.log 2>&1 || exit 1
+timeout -k 10 300 python bench.py --batch 64 $Q > $out/bench_vox64_B64.log 2>&1 || exit 1
+timeout -k 10 300 python bench.py --reg-param 10 $Q > $out/bench_vox64_B16_r1.log 2>&1 || exit 1
+timeout -k 10 300 python bench.py --graph $Q > $out/bench_vox64_B16_graph.log 2>&1 || exit 1
+timeout -k 10 300 python bench.py --workload vox128 $Q > $out/bench_vox128_B2.log 2>&1 || exit 1
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 GIM_FORCE_ALLREDUCE=1 timeout -k 10 300 python bench.py $Q > $out/bench_vox64_B16_rccl1rank.log 2>&1 || exit 1
+for f in om32_B32 vox64_B64 vox64_B16_r1 vox64_B16_graph vox128_B2 vox64_B16_rccl1rank; do echo "$f: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$f.log | head -1) $(grep -o '"bf16x3_path": {"value": [0-9.]*' $out/bench_$f.log)"; done
+timeout -k 10 300 python tools/conv_shapes_bench.py > $out/conv_shapes_fp32.txt 2>&1 || exit 1
+tail -1 $out/conv_shapes_fp32.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x3 > $out/stats.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-bench --no-bf16x3 > $out/pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-bench --no-bf16x3 > $out/pmc_write.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x3 -o r -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-bench > $out/stats_x3.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x3 --no-traffic --no-kernel-bench > $out/stats.log 2>&1 || exit 1
+# PMC of the dominant conv shapes (one counter set per run), forward / dgrad / wgrad with the geometry the step launches
+mkdir -p $out/pmc
+for probe in "fwd 80 32 64 128 3 0 10 0" "dgrad 80 32 64 128 3 0 10 0" "wgrad 80 32 64 128 3 0 10 0" "fwd 160 64 64 64 3 0 10 1" "dgrad 160 64 64 64 3 0 10 1" "wgrad 160 64 64 64 3 0 10 1" "wgrad 80 8 512 512 3 0 10 1"; do
+  name=$(echo $probe | tr ' ' '_')
+  for set in "MfmaUtil" "MeanOccupancyPerActiveCU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
+    sname=$(echo $set | cut -d' ' -f1)
+    timeout -k 10 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc/$name/$sname -o r -- python3 $R/tools/kernel_probe.py $probe > $out/pmc/${name}_$sname.log 2>&1 || { echo "pmc $name $sname failed"; break; }
+  done
+done
 echo measured
