@@ -1064,17 +1064,21 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
             if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>(), std::false_type());
         }
     } else {
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
+    // the LDS buffer of a step is a compile-time constant (two steps per trip): its offset folds into the ds_read / ds_write
+    // immediates instead of costing address VALU next to the MFMAs (every VALU instruction is paid in matrix-pipe time)
+    const float* a_rd = &As[0][0] + h * BM + wm0 + r;
+    const float* b_rd = &Bs[0][0] + h * BN + wn0 + r;
+    auto kstep32 = [&](int ks, auto BUFC) {
+        constexpr int buf = decltype(BUFC)::value;
         if (ks + 1 < nk) load_tiles(mbeg + (ks + 1) * BK, Set0());
         __builtin_amdgcn_sched_barrier(0);  // keep every consumer of the staged registers behind the MFMA block
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[buf][(2 * kp + h) * BM + wm0 + 32 * i + r];
+            for (int i = 0; i < TM; ++i) a[i] = a_rd[buf * A_FLOATS + 2 * kp * BM + 32 * i];
 #pragma unroll
-            for (int jj = 0; jj < TN; ++jj) b[jj] = Bs[buf][(2 * kp + h) * BN + wn0 + 32 * jj + r];
+            for (int jj = 0; jj < TN; ++jj) b[jj] = b_rd[buf * B_FLOATS + 2 * kp * BN + 32 * jj];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1084,7 +1088,13 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         __builtin_amdgcn_sched_barrier(0);
         if (ks + 1 < nk) store_tiles(buf ^ 1, Set0());
         __syncthreads();
+    };
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {   // whole pairs: no control flow between the two steps (a branch there makes the compiler carry
+        kstep32(ks, std::integral_constant<int, 0>());       // the accumulators in VGPRs and copy them to AGPRs every trip)
+        kstep32(ks + 1, std::integral_constant<int, 1>());
     }
+    if (ks < nk) kstep32(ks, std::integral_constant<int, 0>());
     }
 
     if constexpr (X3) {
