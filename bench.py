@@ -410,6 +410,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ms_per_step_median": round(med, 3), "value_at_median_step": round(B * world / med * 1e3, 3),
+            "per_step_ms": [round(t, 2) for t in per_step],   # device time between consecutive steps on the caller's stream (rank 0)
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "config": {"workload": "%s: %dx%dx%d synthetic episodes, m=%d n=%d k=%d, %d episodes/GPU, style_dim=512, "
                                    "G step + D step + 2 Adam updates per step, reg_param=%g" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B, args.reg_param),

@@ -313,9 +313,14 @@ def test_trainer_protocol_vs_reference_golden(tag):
         # at 1e-7 for seven iterations) every Adam(beta1 = 0) update moves each weight by ~lr whatever the gradient's size and the
         # rounding differences grow ~4x per iteration: measured 2e-4 (fp32 MFMA) to 5e-4 (with the R1 term) on iteration 2.
         tol = 1e-4 if it == 0 else 1e-3
+        # The R1 protocol (reg_param = 10) is chaotic at these learning rates from the third update on: the REFERENCE'S OWN
+        # arithmetic in fp32 (the oracle in float32 on the CPU, tools/trainer_fixture_fp32_noise.py ->
+        # profiles/r02_trainer_fixture_fp32_noise.txt) is 2e-4 / 1.3e-2 / 1e-4 off its fp64 run on iteration 2 (g_loss / fake /
+        # d_loss) and 4e-2 on the pass after it; the engine stays an order of magnitude below that (measured 5e-4 / 2e-3).
+        tol_fake = 1.3e-2 if (c["reg_param"] > 0 and it >= 2) else tol
         assert relerr(gres[0], g["it%d/g_loss" % it]) < tol, (it, "g_loss")
         assert relerr(gres[2], g["it%d/g_out" % it]) < tol, (it, "g_out")
-        assert relerr(gres[1], g["it%d/fake" % it]) < tol, (it, "fake")
+        assert relerr(gres[1], g["it%d/fake" % it]) < tol_fake, (it, "fake")
         for i, nm in enumerate(["loss", "loss_real", "loss_fake", "reg", "out_real", "out_fake"]):
             ref = g["it%d/d_%s" % (it, nm)]
             assert relerr(dres[i], ref) < tol or float(np.abs(ref).max()) == 0.0, (it, nm)
@@ -327,9 +332,10 @@ def test_trainer_protocol_vs_reference_golden(tag):
     leaked, real, si, z = [t.float().to(dev()) for t in episode(tag + "/eval", c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
     ge = G.im_eval_step(trainer, leaked, si, z=z)
     de = G.au_eval_step(trainer, real, ge[1], si)
-    assert relerr(ge[0], g["eval/g_loss"]) < 1e-3 and relerr(ge[2], g["eval/g_out"]) < 1e-3
-    assert relerr(de[0], g["eval/d_loss"]) < 1e-3
-    assert relerr(de[4], g["eval/d_out_real"]) < 1e-3 and relerr(de[5], g["eval/d_out_fake"]) < 1e-3
+    etol = 4e-2 if c["reg_param"] > 0 else 1e-3     # the reference's own fp32 drift on this pass of the R1 fixture (see above)
+    assert relerr(ge[0], g["eval/g_loss"]) < etol and relerr(ge[2], g["eval/g_out"]) < etol
+    assert relerr(de[0], g["eval/d_loss"]) < etol
+    assert relerr(de[4], g["eval/d_out_real"]) < etol and relerr(de[5], g["eval/d_out_fake"]) < etol
     for nm, mod in (("au", au), ("im", im)):
         for k_, v in mod.state_dict().items():
             if nm == "au" and k_.endswith(("weight_u", "weight_v")):

@@ -1,0 +1,45 @@
+"""How far the REFERENCE'S OWN arithmetic in fp32 (the oracle run in float32 on the CPU) drifts from its fp64 run on the trainer
+protocol fixtures (tests/golden/trainer_*.npz), per iteration: the noise floor any fp32 implementation sits on.  The R1 fixture
+(reg_param = 10, lr 2e-3 / 1e-3, Adam beta1 = 0) is chaotic from iteration 2 on.   python tools/trainer_fixture_fp32_noise.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import gim_oracle as go  # noqa: E402
+from tests.helpers import episode, filled_sd, load_json, load_keys, load_npz, relerr  # noqa: E402
+
+for tag in ("reg0", "reg10", "nau2"):
+    g, meta = load_npz("trainer_%s.npz" % tag), load_json("trainer_%s.json" % tag)
+    c = meta["config"]
+    keys = load_keys("16_1_32")
+    au = {k: v.float() for k, v in filled_sd(keys["au"], tag + "/au/").items()}
+    im = {k: v.float() for k, v in filled_sd(keys["im"], tag + "/im/").items()}
+    tr = go.OracleTrainer(au, im, c["n"], c["au_lr"], c["im_lr"], c["noise_lr"], reg_param=c["reg_param"])
+    rows = []
+    for it in range(len(meta["meta"]["lrs"])):
+        leaked, real, si, z = [t.float() for t in episode("%s/it%d" % (tag, it), c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
+        scale = c["gamma"] if it + 1 >= c["milestones"][0] else 1.0
+        if (it + 1) % c["n_au_steps"] == 0:
+            tr.im_opt.zero_grad()
+            loss, fake, _ = go.impersonator_forward(au, im, leaked, si, c["n"], z, tr.au_training, True)
+            loss.mean().backward()
+            tr.im_opt.step(lr_scale=scale)
+        else:
+            with torch.no_grad():
+                loss, fake, _ = go.impersonator_forward(au, im, leaked, si, c["n"], z, tr.au_training, False)
+        tr.au_training = True
+        tr.au_opt.zero_grad()
+        res = go.authenticator_forward(au, fake.detach(), real, si, True, c["reg_param"])
+        res[0].mean().backward()
+        tr.au_opt.step(lr_scale=scale)
+        rows.append("it%d: g_loss %.1e fake %.1e d_loss %.1e" % (it, relerr(loss.mean().double(), g["it%d/g_loss" % it]),
+                                                              relerr(fake.double(), g["it%d/fake" % it]),
+                                                              relerr(res[0].detach().mean().double(), g["it%d/d_loss" % it])))
+    leaked, real, si, z = [t.float() for t in episode(tag + "/eval", c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
+    with torch.no_grad():
+        loss, fake, _ = go.impersonator_forward(au, im, leaked, si, c["n"], z, True, False)
+        res = go.authenticator_forward(au, fake, real, si, False, c["reg_param"], grad=False)
+    print(tag, " | ".join(rows), "| eval: g_loss %.1e d_loss %.1e" % (relerr(loss.mean().double(), g["eval/g_loss"]),
+                                                                     relerr(res[0].mean().double(), g["eval/d_loss"])))
