@@ -39,7 +39,9 @@ for tag in ("reg0", "reg10", "nau2"):
                                                               relerr(res[0].detach().mean().double(), g["it%d/d_loss" % it])))
     leaked, real, si, z = [t.float() for t in episode(tag + "/eval", c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
     with torch.no_grad():
-        loss, fake, _ = go.impersonator_forward(au, im, leaked, si, c["n"], z, True, False)
+        loss, fake, g_out = go.impersonator_forward(au, im, leaked, si, c["n"], z, True, False)
         res = go.authenticator_forward(au, fake, real, si, False, c["reg_param"], grad=False)
-    print(tag, " | ".join(rows), "| eval: g_loss %.1e d_loss %.1e" % (relerr(loss.mean().double(), g["eval/g_loss"]),
-                                                                     relerr(res[0].mean().double(), g["eval/d_loss"])))
+    print(tag, " | ".join(rows), "| eval: g_loss %.1e g_out %.1e d_loss %.1e d_out_real %.1e d_out_fake %.1e"
+          % (relerr(loss.mean().double(), g["eval/g_loss"]), relerr(g_out.double(), g["eval/g_out"]),
+             relerr(res[0].mean().double(), g["eval/d_loss"]), relerr(res[4].double().mean(), g["eval/d_out_real"]),
+             relerr(res[5].double().mean(), g["eval/d_out_fake"])))
