@@ -251,8 +251,13 @@ __device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE],
     }
 }
 
+// LDS bytes of the fp32 path's two double-buffered tiles (k-rows padded by 4 floats; the k-major B tile of BMODE 1 is unpadded)
+constexpr int igemm_lds_bytes(int BM, int BN, int KB, int BMODE) {
+    return 2 * (BM * (KB + 4) + (BMODE == 0 ? BN * (KB + 4) : KB * BN)) * 4;
+}
+
 template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB, int PREC = 0>
-__global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)) : (KB == 16 ? 4 : 2)) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)) : (igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 4 : 2)) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
     constexpr bool BSCALAR = (GENF & 2) != 0;
     constexpr bool X3 = PREC == 1;
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         }
     };
 
+    const bool has_act = p.pre_slope != 1.0f;   // wave-uniform
     auto store_tiles = [&](int buf, auto SETC) {
         constexpr int S = decltype(SETC)::value;
         auto& ra = raS[S];
@@ -503,8 +509,12 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
             // fused leaky-relu max(x, slope*x) (slope 1 = identity), IN PLACE and branch-free: a conditional copy of the
             // staged registers gets hoisted above the MFMA block and drags the s_waitcnt vmcnt(0) with it
             // (tools/isa_waitcnt_check.py), which exposes the global-load latency every K-step
+            // (slope 1 - every dgrad, the 1x1 skip convs - skips the 2 VALU per element behind a wave-uniform branch: ordinary
+            // VALU work costs matrix-pipe time)
+            if (has_act) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.pre_slope, p.pos_inf);  // med3(x, s*x, +inf) = max(x, s*x) in 2 VALU (a literal inf folds back into the 3-op canonicalising max)
+                for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.pre_slope, p.pos_inf);  // med3(x, s*x, +inf) = max(x, s*x) in 2 VALU (a literal inf folds back into the 3-op canonicalising max)
+            }
             if constexpr (X3) x3_split_store(reinterpret_cast<unsigned*>(As) + buf * A_SZ + (arow + RP * i) * LDA + (aq >> 1), ra[i]);
             else *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
         }
@@ -1292,9 +1302,8 @@ static int plan_ksplit(long long wgs, int nk, int tile_area, int want_ks) {
 // ({table row found, BM, BN, split-K | wgrad slices, grid x, y, z, matrix path}) and launch nothing.
 static thread_local int32_t* t_plan_out = nullptr;
 
-template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int PREC = 0>
+template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int PREC = 0, int KB = 16>
 static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st, bool table_hit) {
-    constexpr int KB = 16;
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
     const int ncls = p.g.pc ? 4 : 1;
     const int nk = (p.Ktot + KB - 1) / KB;
@@ -1321,6 +1330,20 @@ static void launch_cfg(const ConvP& p, size_t y_elems, hipStream_t st, bool tabl
     launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN>(p, y_elems, st, table_hit);
 }
 
+// 64x64 tile (tile code 64), optionally with K step 32 (tile code 6432: fp32 MFMA fast path with Ca % 32 == 0 only): the small
+// tile does 8 MFMAs per wave and K step, so the per-step costs (barrier, loop, address update, LDS round trip) weigh twice as
+// much as on the 64x128 tile; a 32-deep step halves them at 36 KB of LDS (still 4 workgroups per CU).
+template <int BMODE, int GEN>
+static void launch_64x64(const ConvP& p, size_t y_elems, hipStream_t st, bool table_hit, bool kb32) {
+    if constexpr (GEN == 0) {
+        if (kb32 && p.prec == 0 && p.Ca % 32 == 0) {
+            launch_cfg_kb<64, 64, 1, 1, BMODE, GEN, 0, 32>(p, y_elems, st, table_hit);
+            return;
+        }
+    }
+    launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st, table_hit);
+}
+
 // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K.
 // tune_tile / tune_ks: the caller's explicit choice (gim_conv_shape.tune_tile / tune_ksplit; tune_tile < 0 = heuristics only),
 // else the table row of this shape, else the heuristic.
@@ -1338,11 +1361,11 @@ static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
         int cfg = want ? want : (M <= 64 ? 641 : (t128 < GIM_SMALL_TILES ? 64 : 641));
         if (cfg == 641) launch_cfg<64, 128, 1, 2, BMODE, GEN>(pt, y_elems, st, hit);
         else if (cfg == 1264) launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st, hit);
-        else if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st, hit);
+        else if (cfg == 64 || cfg == 6432) launch_64x64<BMODE, GEN>(pt, y_elems, st, hit, cfg == 6432);
         else launch_cfg<128, 128, 2, 2, BMODE, GEN>(pt, y_elems, st, hit);
     } else if (Cb > 32) {
-        int cfg = (want == 64 || want == 1264) ? want : (M <= 64 ? 64 : 1264);
-        if (cfg == 64) launch_cfg<64, 64, 1, 1, BMODE, GEN>(pt, y_elems, st, hit);
+        int cfg = (want == 64 || want == 6432 || want == 1264) ? want : (M <= 64 ? 64 : 1264);
+        if (cfg == 64 || cfg == 6432) launch_64x64<BMODE, GEN>(pt, y_elems, st, hit, cfg == 6432);
         else launch_cfg<128, 64, 2, 1, BMODE, GEN>(pt, y_elems, st, hit);
     } else if (Cb > 16) {
         launch_cfg<128, 32, 1, 1, BMODE, GEN>(pt, y_elems, st, hit);

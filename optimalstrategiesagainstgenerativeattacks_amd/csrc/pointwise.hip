@@ -165,14 +165,97 @@ __global__ __launch_bounds__(256) void softmax_dim1_bwd_kernel(const float* __re
         ds[o] = p[o] * (dp[o] - dot);
     }
 }
+// The same two operators with the column held in registers (R <= 4 * RPT rows: the 16x16 attention map has R = 256): ONE pass over
+// memory with all of a thread's loads in flight at once instead of three dependent strided sweeps; same arithmetic in the same
+// order, so bit-identical to the kernels above.
+template <int RPT>
+__global__ __launch_bounds__(256) void softmax_dim1_fwd_reg_kernel(const float* __restrict__ s, float* __restrict__ p, int R, int Cc) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const bool ok = col < Cc;
+    const float* sb = s + (long long)b * R * Cc + col;
+    float v[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = rg + 4 * i;
+        v[i] = (ok && r < R) ? sb[(long long)r * Cc] : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) mx = fmaxf(mx, v[i]);
+    red[rg][cl] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][cl], red[1][cl]), fmaxf(red[2][cl], red[3][cl]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = rg + 4 * i;
+        if (ok && r < R) {
+            v[i] = __expf(v[i] - mx);
+            sum += v[i];
+        }
+    }
+    red[rg][cl] = sum;
+    __syncthreads();
+    sum = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (!ok) return;
+    const float inv = 1.0f / sum;
+    float* pb = p + (long long)b * R * Cc + col;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = rg + 4 * i;
+        if (r < R) pb[(long long)r * Cc] = v[i] * inv;
+    }
+}
+template <int RPT>
+__global__ __launch_bounds__(256) void softmax_dim1_bwd_reg_kernel(const float* __restrict__ dp, const float* __restrict__ p, float* __restrict__ ds, int R, int Cc) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const bool ok = col < Cc;
+    const long long base = (long long)b * R * Cc + col;
+    float vp[RPT], vd[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = rg + 4 * i;
+        const bool in = ok && r < R;
+        vp[i] = in ? p[base + (long long)r * Cc] : 0.f;
+        vd[i] = in ? dp[base + (long long)r * Cc] : 0.f;
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = rg + 4 * i;
+        if (ok && r < R) dot += vd[i] * vp[i];
+    }
+    red[rg][cl] = dot;
+    __syncthreads();
+    dot = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = rg + 4 * i;
+        if (r < R) ds[base + (long long)r * Cc] = vp[i] * (vd[i] - dot);
+    }
+}
 extern "C" int gim_softmax_dim1_fwd(const float* s, float* p, int B, int R, int Ccols, void* stream) {
     GIM_CHECK_ARG(s && p && B > 0 && R > 0 && Ccols > 0, "softmax_dim1_fwd: bad args");
-    hipLaunchKernelGGL(softmax_dim1_fwd_kernel, dim3((Ccols + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, s, p, R, Ccols);
+    const dim3 grid((Ccols + 63) / 64, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (R <= 64) hipLaunchKernelGGL(softmax_dim1_fwd_reg_kernel<16>, grid, dim3(256), 0, st, s, p, R, Ccols);
+    else if (R <= 256) hipLaunchKernelGGL(softmax_dim1_fwd_reg_kernel<64>, grid, dim3(256), 0, st, s, p, R, Ccols);
+    else hipLaunchKernelGGL(softmax_dim1_fwd_kernel, grid, dim3(256), 0, st, s, p, R, Ccols);
     return gim_check_launch("gim_softmax_dim1_fwd");
 }
 extern "C" int gim_softmax_dim1_bwd(const float* dp, const float* p, float* ds, int B, int R, int Ccols, void* stream) {
     GIM_CHECK_ARG(dp && p && ds && B > 0 && R > 0 && Ccols > 0, "softmax_dim1_bwd: bad args");
-    hipLaunchKernelGGL(softmax_dim1_bwd_kernel, dim3((Ccols + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dp, p, ds, R, Ccols);
+    const dim3 grid((Ccols + 63) / 64, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (R <= 64) hipLaunchKernelGGL(softmax_dim1_bwd_reg_kernel<16>, grid, dim3(256), 0, st, dp, p, ds, R, Ccols);
+    else if (R <= 256) hipLaunchKernelGGL(softmax_dim1_bwd_reg_kernel<64>, grid, dim3(256), 0, st, dp, p, ds, R, Ccols);
+    else hipLaunchKernelGGL(softmax_dim1_bwd_kernel, grid, dim3(256), 0, st, dp, p, ds, R, Ccols);
     return gim_check_launch("gim_softmax_dim1_bwd");
 }
 

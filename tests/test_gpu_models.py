@@ -150,7 +150,7 @@ def _grad_norm_check(mod, ref, tol, floor_frac, what):
     assert not bad, "%s: %d/%d grad norms off, first: %s" % (what, len(bad), len(ref), bad[:5])
 
 
-def _check_grad_samples(mod, gs, prefix, tol, what):
+def _check_grad_samples(mod, gs, prefix, tol, what, tol_by_prefix=None):
     """nets_<tag>_grads.npz: strided samples g.reshape(-1)[::stride] of whole gradient TENSORS (logical [Cout, Cin, kh, kw]
     order) from the reference - position-sensitive, unlike the per-tensor norms."""
     params = dict(mod.named_parameters())
@@ -161,7 +161,8 @@ def _check_grad_samples(mod, gs, prefix, tol, what):
         _, stride, name = k.split("/", 2)
         got = params[name].grad.detach().double().cpu().reshape(-1)[::int(stride)]
         e = relerr(got, gs[k])
-        assert e < tol, (what, name, "gradient tensor sample", e)
+        t = max([tol] + [v for pfx, v in (tol_by_prefix or {}).items() if name.startswith(pfx)])
+        assert e < t, (what, name, "gradient tensor sample", e)
         n += 1
     assert n >= 5, (what, n)
 
@@ -187,7 +188,11 @@ def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3, use_img_att=False):
     loss.mean().backward()
     _grad_norm_check(im, meta["meta"]["g/im_grad_norms"], gtol, floor_frac, "G step")
     if gs is not None:
-        _check_grad_samples(im, gs, "g/", 1e-3, "G step")
+        # 1e-3, except EnvDecoder tensors: its first blocks normalise 1x1 / 2x2 maps (the instance-norm rule of SURVEY F5) and
+        # amplify rounding - the reference's own arithmetic in fp32 is 1.7e-3 (64x64x3) / 2.2e-4 (32x32x1) off its fp64 run on
+        # env_decoder.up_blocks.2.conv_r1 (tools/grad_sample_fp32_noise.py, profiles/r02_grad_sample_fp32_noise.txt), 4-8e-5 on
+        # the other generator tensors
+        _check_grad_samples(im, gs, "g/", 1e-3, "G step", {"env_decoder.": 6e-3})
     for k in g.files:
         if k.startswith("g/grad/"):
             assert relerr(dict(im.named_parameters())[k[7:]].grad, g[k], atol=1e-7) < gtol, k
@@ -363,7 +368,9 @@ def test_trainer_protocol_vs_reference_golden(tag):
     assert len(tr.impersonator_opt.state_dict()["state"]) >= m_["im_opt_n_state"]
     assert len(tr.impersonator_opt.param_groups) == m_["im_opt_n_groups"]
     first = tr.authenticator_opt.state[next(iter(au.parameters()))]
-    assert abs(float(first["exp_avg_sq"].double().norm()) - m_["au_opt_first_v_norm"]) < 1e-3 * m_["au_opt_first_v_norm"]
+    # (R1 fixture: the third iteration's gradients are already 1e-2 apart between the reference's own fp32 and fp64 runs, see above)
+    vtol = 3e-2 if c["reg_param"] > 0 else 1e-3
+    assert abs(float(first["exp_avg_sq"].double().norm()) - m_["au_opt_first_v_norm"]) < vtol * m_["au_opt_first_v_norm"]
 
 
 def _assert_one_adam_step_matches_oracle(params, buffers, otr, lrs, beta2=0.99, max_share=1e-3):
@@ -949,7 +956,11 @@ def test_train_epoch_vs_reference_loop_golden(monkeypatch):
         elif "acc" in key[0]:
             assert abs(got[key] - v) < 1e-6, (key, got[key], v)
         else:
-            assert abs(got[key] - v) <= 1e-3 * abs(v) + 1e-6, (key, got[key], v)
+            # 1e-3 of the value; statistics that are DIFFERENCES of two encodings (abs[real-si]: 0.004 next to abs[fake-si]: 0.05
+            # and codes of order 0.1) at 1e-3 of the largest value their category logs at that step - relative error of a
+            # cancelling difference says nothing about the operands
+            scale = max(abs(v2) for k2, v2 in want.items() if k2[0] == key[0] and k2[2] == key[2])
+            assert abs(got[key] - v) <= 1e-3 * (scale if key[1].startswith("abs[") else abs(v)) + 1e-6, (key, got[key], v)
     # image dumps: same events in the same order, same content
     assert [e[:4] for e in rec.imgs] == [e[:4] for e in ref["imgs"]]
     for a, b in zip(rec.imgs, ref["imgs"]):

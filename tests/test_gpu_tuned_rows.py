@@ -69,7 +69,7 @@ def test_every_table_row_is_reachable_from_its_shape():
     from optimalstrategiesagainstgenerativeattacks_amd import _lib
     lib = _lib.load()
     api = {0: (0, 0), 1: (1, 0), 2: (3, 0), 3: (0, 1), 4: (2, 1), 5: (3, 1)}   # table kind -> (plan kind, prec)
-    tiles = {128: (128, 128), 641: (64, 128), 1264: (128, 64), 64: (64, 64)}
+    tiles = {128: (128, 128), 641: (64, 128), 1264: (128, 64), 64: (64, 64), 6432: (64, 64)}
     for kind, M, Ca, Cb, Ktot, pc, tile, ks, name, cfg in ROWS:
         plan = _plan(lib, cfg, *api[kind])
         assert plan[0] == 1, ("row not found by its own shape", kind, name, cfg, plan)

@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--append", action="store_true", help="keep the entries already in the table (other workloads)")
     ap.add_argument("--min-gain", type=float, default=0.03)
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad", help="which kernel kinds to tune (comma separated)")
+    ap.add_argument("--out", default=None, help="with --write: write the rows to this file instead of the compiled-in table")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     fwd, bwd = record_shapes(args.workload, args.batch)
@@ -126,6 +127,8 @@ def main():
                 cands = [(tl, 0, tg) for tl in (0, 128, 641, 1264, 64) for tg in (128, 256, 512, 1024, 2048, 4096, 8192)]
             else:
                 tiles = [128, 641, 1264, 64] if Cb > 64 else ([1264, 64] if Cb > 32 else [])
+                if tiles and not x3 and keys[kind][2] % 32 == 0:
+                    tiles.append(6432)   # 64x64 tile with a 32-deep K step (fp32 path only)
                 cands = [(tl, ks, 0) for tl in tiles for ks in (1, 2, 3, 4, 6, 8)]
             for tl, ks, tg in cands:
                 shc = shape(tl if tl else -1, ks, tg)
@@ -146,7 +149,7 @@ def main():
         print("%-6s %-44s x%-3d auto %.3f ms  best %.3f ms (tile %d, ks/target %d)  saves %.3f ms/step"
               % (kind, ",".join(str(c) for c in cfg), calls, t_auto, best[0], best[1], best[2], sav))
     if args.write:
-        path = os.path.join(ROOT, "optimalstrategiesagainstgenerativeattacks_amd", "csrc", "conv_tune_table.inc")
+        path = args.out or os.path.join(ROOT, "optimalstrategiesagainstgenerativeattacks_amd", "csrc", "conv_tune_table.inc")
         old, seen = "", set()
         if args.append and os.path.exists(path):
             old = open(path).read()
