@@ -146,12 +146,12 @@ def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
 # Outputs of split-K launches.  A layer whose output tiles do not fill the chip is sliced along K over the grid and its slices
 # are combined with float atomics into a ZEROED output: ~250 such launches per training step, each with its own memset in front
 # (a 7 us fill kernel plus a kernel boundary).  Instead those outputs are carved out of pages that ONE torch.zeros call clears
-# (per stream, 16 MB at a time): views keep their page alive, so tensor lifetimes are the usual ones; whether a launch splits K
+# (per stream, 64 MB at a time): views keep their page alive, so tensor lifetimes are the usual ones; whether a launch splits K
 # is asked from the library once per shape (gim_conv_launch_plan) and cached.
 _ZERO_POOL = os.environ.get("GIM_NO_ZERO_POOL") is None   # A/B switch (host side)
 _SPLITS_K = {}
 _ZERO_PAGES = {}
-_ZERO_PAGE = 4 << 20   # floats per page (16 MB)
+_ZERO_PAGE = 16 << 20   # floats per page (64 MB)
 
 
 def _splits_k(sh, plan_kind, key):
@@ -166,13 +166,13 @@ def _splits_k(sh, plan_kind, key):
 
 
 def _zeros_from_pool(shape, device):
-    """A zero-filled float32 tensor of `shape`, cleared together with its neighbours by one fill per 16 MB page (pages are per
+    """A zero-filled float32 tensor of `shape`, cleared together with its neighbours by one fill per 64 MB page (pages are per
     stream: the fill and the kernels that use the page are in stream order)."""
     n = 1
     for d in shape:
         n *= d
     na = (n + 63) & ~63
-    if na > _ZERO_PAGE >> 2:     # a big output: its own fill (a view pins its whole page for as long as it lives)
+    if na > _ZERO_PAGE >> 1:     # a big output: its own fill (a view pins its whole page for as long as it lives)
         return torch.zeros(shape, device=device, dtype=torch.float32)
     raw = _stream()
     pg = _ZERO_PAGES.get(raw)

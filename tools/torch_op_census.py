@@ -40,6 +40,15 @@ for ev in prof.events():
     fr = [s for s in (ev.stack or []) if "optimalstrategies" in s or "bench.py" in s]
     stacks[ev.name][" <- ".join(f.split("/")[-1] for f in fr[:3]) or "(autograd engine / torch internals)"] += 1
     shapes[ev.name][str(ev.input_shapes)[:80]] += 1
+allops = collections.Counter(ev.name for ev in prof.events() if ev.name.startswith("aten::") or "Memcpy" in ev.name or "Memset" in ev.name)
+print("all ATen operator / memcpy / memset events per step: " + ", ".join("%s %.0f" % (nm, c / STEPS) for nm, c in allops.most_common(40)))
+for nm in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::zero_", "aten::zeros", "aten::empty_like"):
+    cs = collections.Counter()
+    for ev in prof.events():
+        if ev.name == nm:
+            fr = [s_ for s_ in (ev.stack or []) if "optimalstrategies" in s_ or "bench.py" in s_]
+            cs[" <- ".join(f.split("/")[-1] for f in fr[:3]) or "(autograd engine / torch internals)"] += 1
+    print(nm, ["%.0f %s" % (c / STEPS, k_) for k_, c in cs.most_common(6)])
 print("ATen operators that launched kernels, per step (of %d profiled steps):" % STEPS)
 for name, c in ops.most_common(25):
     print("%-28s %6.1f / step" % (name, c / STEPS))
