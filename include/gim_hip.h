@@ -159,7 +159,9 @@ int gim_conv2d_wgrad_acc(const float* dy, const float* x, float* acc, float* bia
 /* Batched form of gim_wgrad_finish for ALL convolutions / linears of one backward pass (two launches): un-fold, spectral-norm
  * chain rule dW = G/sigma - <G,W>/sigma^2 u v^T (torch.nn.utils.spectral_norm backward; sigma == NULL: plain), ADD into
  * grad_w / grad_b.  tab: n_blocks x {job, chunk} with chunks of 4096 elements of Cout*K*K*Cin; tab_sn: the same for the
- * spectral-norm jobs only.  partial >= n_chunks floats; tmp >= Cout*K*K*Cin floats when fold != 0 and sigma != NULL. */
+ * spectral-norm jobs only.  partial >= n_chunks floats; tmp >= Cout*K*K*Cin floats when fold != 0 and sigma != NULL.
+ * Cout*(K+1)^2*Cin < 2^31 per job (32-bit index arithmetic on the device; the job table lives in device memory, so the
+ * caller checks). */
 typedef struct {
     const float* src;
     const float* bias_src;
@@ -172,7 +174,7 @@ typedef struct {
     float* grad_w;
     float* grad_b;
     int32_t Cout, Cin, K, fold;
-    int32_t n_chunks, reserved;
+    int32_t n_chunks, exclusive;   /* exclusive = 1: no other job of this call adds into grad_w (plain read-modify-write instead of float atomics) */
 } gim_wgrad_job;
 int gim_wgrad_finish_batched(const gim_wgrad_job* jobs, int n_jobs, const int32_t* tab, int n_blocks, const int32_t* tab_sn,
                              int n_blocks_sn, void* stream);

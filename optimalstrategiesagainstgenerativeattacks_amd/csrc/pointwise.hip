@@ -445,12 +445,31 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
     __syncthreads();
     if (rg == 0 && c < C) part[(long long)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
+// Sum of `rows` short rows per column, 64 columns x 4 row groups per block (a single thread walking 80-256 rows of one
+// column is a chain of dependent-latency loads: 20-30 us for a few KB).
+__device__ __forceinline__ float colsum_rows_64x4(const float* __restrict__ x, int rows, int C, int c, int rg, float (*red)[64], int cl) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int r = rg;
+        for (; r + 12 < rows; r += 16) {
+            s0 += x[(long long)r * C + c];
+            s1 += x[(long long)(r + 4) * C + c];
+            s2 += x[(long long)(r + 8) * C + c];
+            s3 += x[(long long)(r + 12) * C + c];
+        }
+        for (; r < rows; r += 4) s0 += x[(long long)r * C + c];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    const float s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    __syncthreads();
+    return s;
+}
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long long)p * C + c];
-    out[c] = s;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const float s = colsum_rows_64x4(part, P, C, c, rg, red, cl);
+    if (rg == 0 && c < C) out[c] = s;
 }
 extern "C" int gim_colsum(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream) {
     GIM_CHECK_ARG(x && out && scratch && rows > 0 && C > 0, "colsum: bad args");
@@ -459,7 +478,7 @@ extern "C" int gim_colsum(const float* x, float* out, float* scratch, int64_t ro
     const long long rows_per = (rows + P - 1) / P;
     P = (rows + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 63) / 64, (int)P), dim3(256), 0, (hipStream_t)stream, x, scratch, (long long)rows, C, rows_per);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)P, C);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)P, C);
     return gim_check_launch("gim_colsum");
 }
 
@@ -784,28 +803,25 @@ extern "C" int gim_episode_gather(const uint8_t* bank, const int32_t* idx, const
 // one launch instead of two two-stage column sums plus two AccumulateGrad adds.
 __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out_a,
                                                       float* __restrict__ out_b, int rows, int C, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float sa = 0.f, sb = 0.f;
-    for (int r = 0; r < rows; ++r) {
-        sa += a[(long long)r * C + c];
-        sb += b[(long long)r * C + c];
-    }
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const float sa = colsum_rows_64x4(a, rows, C, c, rg, red, cl);
+    const float sb = colsum_rows_64x4(b, rows, C, c, rg, red, cl);
+    if (rg != 0 || c >= C) return;
     out_a[c] = accumulate ? out_a[c] + sa : sa;
     out_b[c] = accumulate ? out_b[c] + sb : sb;
 }
 extern "C" int gim_colsum2(const float* a, const float* b, float* out_a, float* out_b, int rows, int C, int accumulate, void* stream) {
     GIM_CHECK_ARG(a && b && out_a && out_b && rows > 0 && C > 0, "colsum2: bad args");
-    hipLaunchKernelGGL(colsum2_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, out_a, out_b, rows, C, accumulate);
+    hipLaunchKernelGGL(colsum2_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, a, b, out_a, out_b, rows, C, accumulate);
     return gim_check_launch("gim_colsum2");
 }
 
 __global__ __launch_bounds__(256) void colsum_final_acc_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long long)p * C + c];
-    out[c] += s;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const float s = colsum_rows_64x4(part, P, C, c, rg, red, cl);
+    if (rg == 0 && c < C) out[c] += s;
 }
 // out[c] += sum_r x[r][c]  (gim_colsum that ADDS: bias gradients straight into the optimizer's gradient bucket)
 extern "C" int gim_colsum_acc(const float* x, float* out, float* scratch, int64_t rows, int C, void* stream) {
@@ -815,6 +831,6 @@ extern "C" int gim_colsum_acc(const float* x, float* out, float* scratch, int64_
     const long long rows_per = (rows + P - 1) / P;
     P = (rows + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 63) / 64, (int)P), dim3(256), 0, (hipStream_t)stream, x, scratch, (long long)rows, C, rows_per);
-    hipLaunchKernelGGL(colsum_final_acc_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)P, C);
+    hipLaunchKernelGGL(colsum_final_acc_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)P, C);
     return gim_check_launch("gim_colsum_acc");
 }

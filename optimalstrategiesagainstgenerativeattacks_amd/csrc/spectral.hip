@@ -282,8 +282,10 @@ __global__ __launch_bounds__(256) void snb_colpart_kernel(const gim_sn_job* __re
     (out_base + jb.off_scratch)[(long long)e.z * K + p] = acc;
 }
 
-__global__ __launch_bounds__(256) void snb_vnorm_kernel(const gim_sn_job* __restrict__ jobs, float* __restrict__ out_base, int training) {
-    __shared__ float red[4];
+// One block of 1024 threads per job (the jobs are few - one per conv - and a 256-thread block walking the 4608-5120 columns of
+// the largest ones was a 46 us chain of dependent-latency loads at the head of every forward pass).
+__global__ __launch_bounds__(1024) void snb_vnorm_kernel(const gim_sn_job* __restrict__ jobs, float* __restrict__ out_base, int training) {
+    __shared__ float red[16];
     const gim_sn_job jb = jobs[blockIdx.x];
     const int T = jb.KH * jb.KH, K = jb.Cin * T;
     const int R = min(SN_R, (jb.Cout + 63) / 64);
@@ -292,14 +294,20 @@ __global__ __launch_bounds__(256) void snb_vnorm_kernel(const gim_sn_job* __rest
     float* v_out = out_base + jb.off_v;
     if (training) {
         float ss = 0.f;
-        for (int p = threadIdx.x; p < K; p += 256) {
+        for (int p = threadIdx.x; p < K; p += 1024) {
             float a = 0.f;
             for (int r = 0; r < R; ++r) a += part[(long long)r * K + p];
             v_phys[p] = a;
             ss += a * a;
         }
-        const float inv = 1.0f / fmaxf(sqrtf(block_sum_256(ss, red)), 1e-12f);
-        for (int p = threadIdx.x; p < K; p += 256) {
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i];
+        const float inv = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+        for (int p = threadIdx.x; p < K; p += 1024) {   // each thread re-reads only what it wrote itself
             const float val = v_phys[p] * inv;
             const int tap = p / jb.Cin, ci = p - tap * jb.Cin;
             const int q = ci * T + tap;
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256) void snb_vnorm_kernel(const gim_sn_job* __rest
             v_out[q] = val;
         }
     } else {
-        for (int q = threadIdx.x; q < K; q += 256) {
+        for (int q = threadIdx.x; q < K; q += 1024) {
             const int ci = q / T, tap = q - ci * T;
             const float val = jb.v[q];
             v_phys[tap * jb.Cin + ci] = val;
@@ -369,7 +377,7 @@ extern "C" int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, co
     hipStream_t st = (hipStream_t)stream;
     if (training)
         hipLaunchKernelGGL(snb_colpart_kernel, dim3(n_col_blocks), dim3(256), 0, st, jobs, reinterpret_cast<const int4*>(tab_cols), out_base);
-    hipLaunchKernelGGL(snb_vnorm_kernel, dim3(n_jobs), dim3(256), 0, st, jobs, out_base, training);
+    hipLaunchKernelGGL(snb_vnorm_kernel, dim3(n_jobs), dim3(1024), 0, st, jobs, out_base, training);
     hipLaunchKernelGGL(snb_rowdot_kernel, dim3(n_row_blocks), dim3(256), 0, st, jobs, reinterpret_cast<const int2*>(tab_rows), out_base);
     hipLaunchKernelGGL(snb_final_kernel, dim3(n_jobs), dim3(256), 0, st, jobs, out_base, training);
     return gim_check_launch("gim_spectral_sigma_batched");
@@ -383,43 +391,68 @@ extern "C" int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, co
 // -------------------------------------------------------------------------------------------------
 #define WGQ_CHUNK 4096
 
-__device__ __forceinline__ float wgq_load(const gim_wgrad_job& jb, long long i) {
+// (All index arithmetic is 32-bit - the caller guarantees Cout*(K+1)^2*Cin < 2^31 per job, ops.WgradQueue checks it: the first
+//  version's 64-bit divisions per element made these two HBM-bound passes 3x slower than the bytes they move.)
+__device__ __forceinline__ float wgq_load(const gim_wgrad_job& jb, unsigned i) {
     if (jb.fold == 0) return jb.src[i];
-    const int K = jb.K, KF = K + 1, Cin = jb.Cin, Cout = jb.Cout;
-    const int ci = (int)(i % Cin);
-    long long rr = i / Cin;
-    const int kw = (int)(rr % K); rr /= K;
-    const int kh = (int)(rr % K);
-    const int co = (int)(rr / K);
+    const unsigned K = jb.K, KF = K + 1, Cin = jb.Cin, Cout = jb.Cout;
+    const unsigned r1 = i / Cin, ci = i - r1 * Cin;
+    const unsigned r2 = r1 / K, kw = r1 - r2 * K;
+    const unsigned co = r2 / K, kh = r2 - co * K;
     float g = 0.f;
 #pragma unroll
-    for (int dh = 0; dh < 2; ++dh)
+    for (unsigned dh = 0; dh < 2; ++dh)
 #pragma unroll
-        for (int dwd = 0; dwd < 2; ++dwd) {
-            const int a = kh + dh, b = kw + dwd;
-            if (jb.fold == 1) g += jb.src[(((long long)co * KF + a) * KF + b) * Cin + ci];
-            else g += jb.src[(((long long)ci * KF + (K - a)) * KF + (K - b)) * Cout + co];
+        for (unsigned dwd = 0; dwd < 2; ++dwd) {
+            const unsigned a = kh + dh, b = kw + dwd;
+            if (jb.fold == 1) g += jb.src[((co * KF + a) * KF + b) * Cin + ci];
+            else g += jb.src[((ci * KF + (K - a)) * KF + (K - b)) * Cout + co];
         }
     return jb.fold == 1 ? 0.25f * g : g;
+}
+
+__device__ __forceinline__ bool wgq_aligned16(const void* a, const void* b, const void* c) {
+    return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
 }
 
 __global__ __launch_bounds__(256) void wgq_reduce_kernel(const gim_wgrad_job* __restrict__ jobs, const int2* __restrict__ tab) {
     __shared__ float red[4];
     const int2 e = tab[blockIdx.x];  // {job, chunk}
     const gim_wgrad_job jb = jobs[e.x];
-    const long long n = (long long)jb.Cout * jb.K * jb.K * jb.Cin;
-    const long long i0 = (long long)e.y * WGQ_CHUNK;
+    const unsigned n = (unsigned)jb.Cout * jb.K * jb.K * jb.Cin;
+    const unsigned i0 = (unsigned)e.y * WGQ_CHUNK;
+    const unsigned cnt = min((unsigned)WGQ_CHUNK, n - i0);
     const bool sn = jb.sigma != nullptr;
     float dot = 0.f;
-    for (int t = threadIdx.x; t < WGQ_CHUNK; t += 256) {
-        const long long i = i0 + t;
-        if (i >= n) break;
-        const float g = wgq_load(jb, i);
-        if (sn) {
-            if (jb.fold) jb.tmp[i] = g;
-            dot += g * jb.w[i];
-        } else {
-            atomicAdd(&jb.grad_w[i], g);  // several jobs (calls of the same conv) may target one gradient
+    if (sn && jb.fold == 0 && (n & 3) == 0 && wgq_aligned16(jb.src, jb.w, jb.w)) {
+        // <G, W> only (the apply kernel reads G again): 16-byte loads
+        for (unsigned t = threadIdx.x * 4; t < cnt; t += 1024) {
+            const float4 g = *reinterpret_cast<const float4*>(jb.src + i0 + t);
+            const float4 w = *reinterpret_cast<const float4*>(jb.w + i0 + t);
+            dot += g.x * w.x + g.y * w.y + g.z * w.z + g.w * w.w;
+        }
+    } else if (!sn && jb.fold == 0 && jb.exclusive && (n & 3) == 0 && wgq_aligned16(jb.src, jb.grad_w, jb.grad_w)) {
+        // the only job of this gradient in the pass: plain 16-byte read-modify-write instead of float atomics
+        for (unsigned t = threadIdx.x * 4; t < cnt; t += 1024) {
+            const float4 g = *reinterpret_cast<const float4*>(jb.src + i0 + t);
+            float4* dst = reinterpret_cast<float4*>(jb.grad_w + i0 + t);
+            float4 o = *dst;
+            o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w;
+            *dst = o;
+        }
+    } else {
+        // lane-consecutive elements: the float atomics of a wave then hit 256 consecutive bytes (4 elements per lane made every
+        // atomic instruction span 1 KB and the pass 1.4x slower than the scalar form)
+#pragma unroll 4
+        for (unsigned t = threadIdx.x; t < cnt; t += 256) {
+            const unsigned i = i0 + t;
+            const float g = wgq_load(jb, i);
+            if (sn) {
+                if (jb.fold) jb.tmp[i] = g;
+                dot += g * jb.w[i];
+            } else {   // several jobs (calls of the same conv) may target one gradient
+                atomicAdd(&jb.grad_w[i], g);
+            }
         }
     }
     if (sn) {
@@ -439,16 +472,48 @@ __global__ __launch_bounds__(256) void wgq_apply_kernel(const gim_wgrad_job* __r
     d = block_sum_256(d, red);
     const float inv = 1.0f / jb.sigma[0];
     const float coef = d * inv * inv;
-    const int T = jb.K * jb.K, Kc = jb.Cin * T;
-    const long long n = (long long)jb.Cout * Kc;
-    const long long i0 = (long long)e.y * WGQ_CHUNK;
+    const unsigned Cin = jb.Cin, T = (unsigned)jb.K * jb.K, Kc = Cin * T;
+    const unsigned n = (unsigned)jb.Cout * Kc;
+    const unsigned i0 = (unsigned)e.y * WGQ_CHUNK;
+    const unsigned cnt = min((unsigned)WGQ_CHUNK, n - i0);
     const float* __restrict__ g = jb.fold ? jb.tmp : jb.src;
-    for (int t = threadIdx.x; t < WGQ_CHUNK; t += 256) {
-        const long long i = i0 + t;
-        if (i >= n) break;
-        const int co = (int)(i / Kc);
-        const int p = (int)(i - (long long)co * Kc);
-        const int tap = p / jb.Cin, ci = p - tap * jb.Cin;
+    // (co, p) of the chunk's first element once per block; per element a carry (only layers with fewer than 4096 weights per
+    // output channel wrap more than once) and ONE 32-bit division by Cin
+    const unsigned co0 = i0 / Kc, p0 = i0 - co0 * Kc;
+    if (jb.exclusive && (Cin & 3) == 0 && wgq_aligned16(g, jb.grad_w, jb.grad_w)) {
+        // the only job of this gradient in the pass: 16-byte read-modify-write (4 consecutive input channels share the output
+        // channel and the tap)
+        for (unsigned t = threadIdx.x * 4; t < cnt; t += 1024) {
+            unsigned p = p0 + t, co = co0;
+            if (p >= Kc) {
+                const unsigned q = p / Kc;
+                co += q;
+                p -= q * Kc;
+            }
+            const unsigned tap = p / Cin, ci = p - tap * Cin;
+            const float4 gv = *reinterpret_cast<const float4*>(g + i0 + t);
+            const float cu = coef * jb.u[co];
+            const float* v = jb.v + ci * T + tap;
+            float4* dst = reinterpret_cast<float4*>(jb.grad_w + i0 + t);
+            float4 o = *dst;
+            o.x += gv.x * inv - cu * v[0];
+            o.y += gv.y * inv - cu * v[T];
+            o.z += gv.z * inv - cu * v[2 * T];
+            o.w += gv.w * inv - cu * v[3 * T];
+            *dst = o;
+        }
+        return;
+    }
+#pragma unroll 4
+    for (unsigned t = threadIdx.x; t < cnt; t += 256) {
+        unsigned p = p0 + t, co = co0;
+        if (p >= Kc) {
+            const unsigned q = p / Kc;
+            co += q;
+            p -= q * Kc;
+        }
+        const unsigned tap = p / Cin, ci = p - tap * Cin;
+        const unsigned i = i0 + t;
         atomicAdd(&jb.grad_w[i], g[i] * inv - coef * jb.u[co] * jb.v[ci * T + tap]);
     }
 }

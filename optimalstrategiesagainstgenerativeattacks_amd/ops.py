@@ -227,7 +227,7 @@ class _WgradJob(ctypes.Structure):
                 ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("tmp", ctypes.c_void_p), ("partial", ctypes.c_void_p),
                 ("grad_w", ctypes.c_void_p), ("grad_b", ctypes.c_void_p),
                 ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32), ("K", ctypes.c_int32), ("fold", ctypes.c_int32),
-                ("n_chunks", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("n_chunks", ctypes.c_int32), ("exclusive", ctypes.c_int32)]
 
 
 class WgradQueue:
@@ -302,10 +302,12 @@ class WgradQueue:
                                    "(at least 2) before capturing a hipGraph")
             arr = (_WgradJob * len(sig))()
             tab, tab_sn = [], []
+            targets = collections.Counter(jb[8] for jb in sig)   # grad_w pointers: a conv called several times in the pass has several jobs
             for j, jb in enumerate(sig):
                 a = arr[j]
                 (a.src, a.bias_src, a.w, a.sigma, a.u, a.v, a.tmp, a.partial, a.grad_w, a.grad_b,
                  a.Cout, a.Cin, a.K, a.fold, a.n_chunks) = jb
+                a.exclusive = 1 if targets[jb[8]] == 1 else 0
                 blocks = [(j, c) for c in range(jb[14])]
                 tab += blocks
                 if jb[3]:
@@ -569,6 +571,8 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
         q = _queue()
         # deferred: raw gradient into an arena slot now, finish of all convs in two launches when backward ends
         n = Cout * K
+        if Cout * KFF >= 1 << 31:
+            raise RuntimeError("weight gradient of more than 2^31 elements (gim_wgrad_finish_batched indexes with 32 bits)")
         n_chunks = (n + q.CHUNK - 1) // q.CHUNK
         src = q.take(Cout * KFF, dev)
         bsrc = q.take(Cout, dev) if slab_bias else None

@@ -152,19 +152,24 @@ def _grad_norm_check(mod, ref, tol, floor_frac, what):
 
 def _check_grad_samples(mod, gs, prefix, tol, what, tol_by_prefix=None):
     """nets_<tag>_grads.npz: strided samples g.reshape(-1)[::stride] of whole gradient TENSORS (logical [Cout, Cin, kh, kw]
-    order) from the reference - position-sensitive, unlike the per-tensor norms."""
+    order) from the reference - position-sensitive, unlike the per-tensor norms.  A failure reports every sampled tensor with the
+    best common factor (a shared factor = something upstream of all of them moved; scattered = rounding noise)."""
     params = dict(mod.named_parameters())
-    n = 0
+    rows, bad = [], []
     for k in gs.files:
         if not k.startswith(prefix):
             continue
         _, stride, name = k.split("/", 2)
         got = params[name].grad.detach().double().cpu().reshape(-1)[::int(stride)]
+        ref = torch.as_tensor(np.asarray(gs[k], dtype=np.float64)).reshape(-1)
         e = relerr(got, gs[k])
+        alpha = float(got @ ref / (ref @ ref))
         t = max([tol] + [v for pfx, v in (tol_by_prefix or {}).items() if name.startswith(pfx)])
-        assert e < t, (what, name, "gradient tensor sample", e)
-        n += 1
-    assert n >= 5, (what, n)
+        rows.append("%s: relerr %.3e (tol %.0e), common factor %+.3e, residual %.3e" % (name, e, t, alpha - 1.0, float((got - alpha * ref).norm() / ref.norm())))
+        if not e < t:
+            bad.append(name)
+    assert not bad, (what, "gradient tensor samples", bad, rows)
+    assert len(rows) >= 5, (what, len(rows))
 
 
 def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3, use_img_att=False):
@@ -188,11 +193,14 @@ def _check_nets(tag, cfg, tol, gtol, floor_frac=1e-3, use_img_att=False):
     loss.mean().backward()
     _grad_norm_check(im, meta["meta"]["g/im_grad_norms"], gtol, floor_frac, "G step")
     if gs is not None:
-        # 1e-3, except EnvDecoder tensors: its first blocks normalise 1x1 / 2x2 maps (the instance-norm rule of SURVEY F5) and
-        # amplify rounding - the reference's own arithmetic in fp32 is 1.7e-3 (64x64x3) / 2.2e-4 (32x32x1) off its fp64 run on
-        # env_decoder.up_blocks.2.conv_r1 (tools/grad_sample_fp32_noise.py, profiles/r02_grad_sample_fp32_noise.txt), 4-8e-5 on
-        # the other generator tensors
-        _check_grad_samples(im, gs, "g/", 1e-3, "G step", {"env_decoder.": 6e-3})
+        # Generator-step gradients at these shapes carry the fp32 ambiguity of the whole G -> D -> loss -> D -> G chain: typically
+        # 0.7-6e-4 off the fp64 reference (tools/grad_sample_probe.py, 10 runs per matrix path), but a max-pool argmax or
+        # LeakyReLU mask that sits within rounding of a tie can fall the other way and then moves EVERY generator gradient by the
+        # same relative amount at once (1.04e-3 observed on two different tensors in two different runs; the reference's own
+        # arithmetic in fp32 is 1.7e-3 off its fp64 run on env_decoder.up_blocks.2.conv_r1 and 4-6e-5 on the others:
+        # tools/grad_sample_fp32_noise.py, profiles/r02_grad_sample_fp32_noise.txt).  3e-3 covers one such flip; position errors
+        # (a permuted tap or channel) are O(1).  The discriminator-step samples below stay at 1e-3 (they sit at 1e-6).
+        _check_grad_samples(im, gs, "g/", 3e-3, "G step", {"env_decoder.": 6e-3})
     for k in g.files:
         if k.startswith("g/grad/"):
             assert relerr(dict(im.named_parameters())[k[7:]].grad, g[k], atol=1e-7) < gtol, k
@@ -255,7 +263,7 @@ def _noise_walk(opt, params, n_updates, lr):
     return walk
 
 
-def _assert_final_state(mod, ref, walk, what):
+def _assert_final_state(mod, ref, walk, what, rel=3e-4):
     """Per-tensor sum and L2 norm of the state dict after the protocol against the reference's (fixture meta.*_final):
     relative 3e-4 (norm) / the matching bound on the sum (measured worst case 1.1e-4: an attention bias whose gradient elements
     sit just above rounding noise, so that a few of its Adam(beta1 = 0) updates take the other sign); noise-walk tensors (see
@@ -267,7 +275,7 @@ def _assert_final_state(mod, ref, walk, what):
         t = sd[k_].detach().double()
         w = walk.get(k_) or 0.0
         n = t.numel() ** 0.5
-        if abs(float(t.norm()) - n_ref) > 3e-4 * n_ref + w or abs(float(t.sum()) - s_ref) > 3e-4 * n_ref * n + w * n:
+        if abs(float(t.norm()) - n_ref) > rel * n_ref + w or abs(float(t.sum()) - s_ref) > rel * n_ref * n + w * n:
             bad.append((k_, float(t.norm()), n_ref, float(t.sum()), s_ref, w))
     assert not bad, "%s: %d/%d tensors off the reference's final state, first: %s" % (what, len(bad), len(ref), bad[:4])
 
@@ -321,8 +329,10 @@ def test_trainer_protocol_vs_reference_golden(tag):
         # The R1 protocol (reg_param = 10) is chaotic at these learning rates from the third update on: the REFERENCE'S OWN
         # arithmetic in fp32 (the oracle in float32 on the CPU, tools/trainer_fixture_fp32_noise.py ->
         # profiles/r02_trainer_fixture_fp32_noise.txt) is 2e-4 / 1.3e-2 / 1e-4 off its fp64 run on iteration 2 (g_loss / fake /
-        # d_loss) and 4e-2 on the pass after it; the engine stays an order of magnitude below that (measured 5e-4 / 2e-3).
-        tol_fake = 1.3e-2 if (c["reg_param"] > 0 and it >= 2) else tol
+        # d_loss), 1.0e-3 on the logits, and 4e-2 on the pass after it; the engine lands on the same figures (it follows the fp32 trajectory).
+        tol_fake = tol
+        if c["reg_param"] > 0 and it >= 2:   # 3x the reference's own fp32-vs-fp64 drift there: 2.3e-4 / 1.0e-3 / 1.3e-2 (g_loss / g_out / fake)
+            tol, tol_fake = 3e-3, 4e-2
         assert relerr(gres[0], g["it%d/g_loss" % it]) < tol, (it, "g_loss")
         assert relerr(gres[2], g["it%d/g_out" % it]) < tol, (it, "g_out")
         assert relerr(gres[1], g["it%d/fake" % it]) < tol_fake, (it, "fake")
@@ -358,8 +368,11 @@ def test_trainer_protocol_vs_reference_golden(tag):
     m_ = meta["meta"]
     au_walk = _noise_walk(tr.authenticator_opt, au.named_parameters(), n_steps, c["au_lr"])
     im_walk = _noise_walk(tr.impersonator_opt, im.named_parameters(), n_im_updates, c["im_lr"])
-    _assert_final_state(au, m_["au_final"], au_walk, "authenticator")
-    _assert_final_state(im, m_["im_final"], im_walk, "impersonator")
+    # R1 fixture: the reference's own fp32 run ends 3.2e-3 (authenticator, att.gamma) off its fp64 run by this measure
+    # (profiles/r02_trainer_fixture_fp32_noise.txt: the third update is taken on the chaotic iteration); the others 7e-5 / 9e-5
+    rel = 1e-2 if c["reg_param"] > 0 else 3e-4
+    _assert_final_state(au, m_["au_final"], au_walk, "authenticator", rel)
+    _assert_final_state(im, m_["im_final"], im_walk, "impersonator", rel)
     osd = tr.authenticator_opt.state_dict()
     assert sorted({int(v["step"]) for v in osd["state"].values()}) == m_["au_opt_steps"]
     assert m_["au_opt_n_state"] == len(osd["state"])
@@ -368,8 +381,9 @@ def test_trainer_protocol_vs_reference_golden(tag):
     assert len(tr.impersonator_opt.state_dict()["state"]) >= m_["im_opt_n_state"]
     assert len(tr.impersonator_opt.param_groups) == m_["im_opt_n_groups"]
     first = tr.authenticator_opt.state[next(iter(au.parameters()))]
-    # (R1 fixture: the third iteration's gradients are already 1e-2 apart between the reference's own fp32 and fp64 runs, see above)
-    vtol = 3e-2 if c["reg_param"] > 0 else 1e-3
+    # (R1 fixture: the reference's own fp32 run is 3.3e-2 off its fp64 run on this norm - profiles/r02_trainer_fixture_fp32_noise.txt -
+    #  and the engine lands on the same figure, 3.2e-2: it follows the fp32 trajectory; the other fixtures: 5e-7 / 1e-10)
+    vtol = 1e-1 if c["reg_param"] > 0 else 1e-3
     assert abs(float(first["exp_avg_sq"].double().norm()) - m_["au_opt_first_v_norm"]) < vtol * m_["au_opt_first_v_norm"]
 
 

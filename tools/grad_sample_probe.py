@@ -1,0 +1,44 @@
+"""Engine vs the reference's gradient-tensor samples (tests/golden/nets_<tag>_grads.npz) at the benchmark shapes, per tensor: relative
+error, and the same after fitting one scalar (a common factor would point at a loss-side scale, scattered values at rounding noise).
+    python tools/grad_sample_probe.py [prec=0|1]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import optimalstrategiesagainstgenerativeattacks_amd as G  # noqa: E402
+from optimalstrategiesagainstgenerativeattacks_amd import ops  # noqa: E402
+from tests.helpers import episode, load_json, load_npz, relerr  # noqa: E402
+from tests.test_gpu_models import _product_models, dev  # noqa: E402
+
+ops.set_conv_precision(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+for tag, cfg in (("om32_f64", "32_1_512"), ("vox64_f64", "64_3_512")):
+    g = load_npz("nets_%s.npz" % tag)
+    gs = load_npz("nets_%s_grads.npz" % tag)
+    c = load_json("nets_%s.json" % tag)["config"]
+    for rep in range(REPS):
+        au, im = _product_models(tag, cfg, False)
+        leaked, real, si, z = [t.float().to(dev()) for t in episode(tag, c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
+        with tempfile.TemporaryDirectory() as td:
+            tr = G.GIMImgTrainer(td, c["m"], c["n"], c["k"], au, im, 1e-4, 1e-4, 1e-6, reg_param=0.0)
+        au.train(); im.train()
+        tr.impersonator_opt.zero_grad()
+        loss, fake, out = tr.forward(mode="impersonator_forward", leaked_sample=leaked, si_sample=si, z=z)
+        loss.mean().backward()
+        print("%s run %d (matrix path %d): G loss %.2e, logits %.2e, fake %.2e" % (tag, rep, ops.conv_precision(), relerr(loss, g["g/loss"]),
+                                                                                   relerr(out, g["g/out"]), relerr(fake[:g["g/fake"].shape[0], :g["g/fake"].shape[1]], g["g/fake"])))
+        params = dict(im.named_parameters())
+        for k in gs.files:
+            if not k.startswith("g/"):
+                continue
+            _, stride, name = k.split("/", 2)
+            got = params[name].grad.detach().double().cpu().reshape(-1)[::int(stride)].numpy()
+            ref = np.asarray(gs[k], dtype=np.float64).reshape(-1)
+            alpha = float(got @ ref / (ref @ ref))
+            print("   %-62s relerr %.2e   best common factor %+.2e -> residual %.2e" % (name, relerr(torch.from_numpy(got), ref), alpha - 1.0,
+                                                                                         float(np.linalg.norm(got - alpha * ref) / np.linalg.norm(ref))))

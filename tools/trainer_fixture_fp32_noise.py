@@ -23,25 +23,36 @@ for tag in ("reg0", "reg10", "nau2"):
         scale = c["gamma"] if it + 1 >= c["milestones"][0] else 1.0
         if (it + 1) % c["n_au_steps"] == 0:
             tr.im_opt.zero_grad()
-            loss, fake, _ = go.impersonator_forward(au, im, leaked, si, c["n"], z, tr.au_training, True)
+            loss, fake, gout = go.impersonator_forward(au, im, leaked, si, c["n"], z, tr.au_training, True)
             loss.mean().backward()
             tr.im_opt.step(lr_scale=scale)
         else:
             with torch.no_grad():
-                loss, fake, _ = go.impersonator_forward(au, im, leaked, si, c["n"], z, tr.au_training, False)
+                loss, fake, gout = go.impersonator_forward(au, im, leaked, si, c["n"], z, tr.au_training, False)
         tr.au_training = True
         tr.au_opt.zero_grad()
         res = go.authenticator_forward(au, fake.detach(), real, si, True, c["reg_param"])
         res[0].mean().backward()
         tr.au_opt.step(lr_scale=scale)
-        rows.append("it%d: g_loss %.1e fake %.1e d_loss %.1e" % (it, relerr(loss.mean().double(), g["it%d/g_loss" % it]),
-                                                              relerr(fake.double(), g["it%d/fake" % it]),
-                                                              relerr(res[0].detach().mean().double(), g["it%d/d_loss" % it])))
+        rows.append("it%d: g_loss %.1e g_out %.1e fake %.1e d_loss %.1e"
+                    % (it, relerr(loss.mean().double(), g["it%d/g_loss" % it]), relerr(gout.detach().double(), g["it%d/g_out" % it]),
+                       relerr(fake.double(), g["it%d/fake" % it]), relerr(res[0].detach().mean().double(), g["it%d/d_loss" % it])))
     leaked, real, si, z = [t.float() for t in episode(tag + "/eval", c["B"], c["m"], c["n"], c["k"], c["c"], c["s"], c["d"])]
     with torch.no_grad():
         loss, fake, g_out = go.impersonator_forward(au, im, leaked, si, c["n"], z, True, False)
         res = go.authenticator_forward(au, fake, real, si, False, c["reg_param"], grad=False)
-    print(tag, " | ".join(rows), "| eval: g_loss %.1e g_out %.1e d_loss %.1e d_out_real %.1e d_out_fake %.1e"
+    fin = []
+    for nm, sd in (("au", au), ("im", im)):
+        worst = (0.0, "")
+        for k, (s_ref, n_ref) in meta["meta"][nm + "_final"].items():
+            t = sd[k].detach().double()
+            dev_ = max(abs(float(t.norm()) - n_ref) / max(n_ref, 1e-30), abs(float(t.sum()) - s_ref) / max(n_ref * t.numel() ** 0.5, 1e-30))
+            worst = max(worst, (dev_, k))
+        fin.append("%s final state: worst tensor %.1e (%s)" % (nm, worst[0], worst[1]))
+    first = next(k for k in au if go.is_param(k))
+    fin.append("au Adam v of the first parameter (%s): norm %.1e off" % (first, abs(float(tr.au_opt.state[first]["v"].double().norm()) - meta["meta"]["au_opt_first_v_norm"])
+                                                                        / meta["meta"]["au_opt_first_v_norm"]))
+    print(tag, " | ".join(rows), "|", " ; ".join(fin), "|", "eval: g_loss %.1e g_out %.1e d_loss %.1e d_out_real %.1e d_out_fake %.1e"
           % (relerr(loss.mean().double(), g["eval/g_loss"]), relerr(g_out.double(), g["eval/g_out"]),
              relerr(res[0].mean().double(), g["eval/d_loss"]), relerr(res[4].double().mean(), g["eval/d_out_real"]),
              relerr(res[5].double().mean(), g["eval/d_out_fake"])))
