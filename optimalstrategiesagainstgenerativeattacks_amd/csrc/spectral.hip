@@ -424,7 +424,35 @@ __global__ __launch_bounds__(256) void wgq_reduce_kernel(const gim_wgrad_job* __
     const unsigned cnt = min((unsigned)WGQ_CHUNK, n - i0);
     const bool sn = jb.sigma != nullptr;
     float dot = 0.f;
-    if (sn && jb.fold == 0 && (n & 3) == 0 && wgq_aligned16(jb.src, jb.w, jb.w)) {
+    if (sn && jb.fold == 2 && (jb.Cout & 63) == 0 && (jb.Cin & 63) == 0) {
+        // Sub-pixel (role-swapped) jobs hold G[ci][KF][KF][co]; the gradient wants [co][K][K][ci].  Read by flat output index,
+        // consecutive lanes (ci) are KF*KF*Cout floats apart in G - one 64-byte sector per lane and load.  Instead this block takes
+        // a 64 co x 64 ci tile of ONE tap (the chunk id is re-read as (co tile, ci tile, tap): the same 4096 elements per block,
+        // every element covered once, so `partial` and `tmp` keep their meaning), reads G along co, turns the tile in LDS and
+        // writes along ci.
+        __shared__ float tile[64][65];
+        const unsigned K = jb.K, KF = K + 1, T = K * K, Cin = jb.Cin, Cout = jb.Cout, tiles_ci = Cin >> 6;
+        const unsigned tap = (unsigned)e.y % T, r = (unsigned)e.y / T;
+        const unsigned ci0 = (r % tiles_ci) << 6, co0 = (r / tiles_ci) << 6;
+        const unsigned kh = tap / K, kw = tap - kh * K;
+        const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll 4
+        for (unsigned j = 0; j < 16; ++j) {
+            const unsigned ci = ci0 + wv + 4 * j;
+            const float* base = jb.src + (((size_t)ci * KF + (K - kh)) * KF + (K - kw)) * Cout + co0 + lane;
+            // taps (K-kh-dh, K-kw-dw), dh, dw in {0, 1}
+            tile[wv + 4 * j][lane] = (base[0] + base[-(long)Cout]) + (base[-(long)(KF * Cout)] + base[-(long)((KF + 1) * Cout)]);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (unsigned j = 0; j < 16; ++j) {
+            const unsigned co = co0 + wv + 4 * j;
+            const float g = tile[lane][wv + 4 * j];
+            const unsigned i = ((co * K + kh) * K + kw) * Cin + ci0 + lane;
+            jb.tmp[i] = g;
+            dot += g * jb.w[i];
+        }
+    } else if (sn && jb.fold == 0 && (n & 3) == 0 && wgq_aligned16(jb.src, jb.w, jb.w)) {
         // <G, W> only (the apply kernel reads G again): 16-byte loads
         for (unsigned t = threadIdx.x * 4; t < cnt; t += 1024) {
             const float4 g = *reinterpret_cast<const float4*>(jb.src + i0 + t);

@@ -1,6 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02r; mkdir -p $out
-sed -i 's/_check_grad_samples(im, gs, "g\/", 3e-3, "G step", {"env_decoder.": 6e-3})/_check_grad_samples(im, gs, "g\/", 1e-3, "G step", {"env_decoder.": 1e-3})/' tests/test_gpu_models.py
-timeout -k 10 600 python -m pytest tests/test_gpu_bf16x3.py -m gpu -q > $out/pytest_x3.log 2>&1; echo "x3 file (strict 1e-3): $(tail -1 $out/pytest_x3.log)"; grep -o "common factor [^,]*, residual [^']*" $out/pytest_x3.log | head -12
-timeout -k 10 600 python -m pytest tests/test_gpu_models.py -m gpu -q -k "golden" > $out/pytest_models.log 2>&1; echo "models golden (strict 1e-3): $(tail -1 $out/pytest_models.log)"; grep -o "common factor [^,]*, residual [^']*" $out/pytest_models.log | head -12
+out=gpurun_out/r02s; mkdir -p $out
+timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py tests/test_gpu_bf16x3.py -m gpu -q > $out/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc: $(tail -1 $out/pytest.log)"; grep -E "^FAILED|^ERROR" $out/pytest.log | head
+[ $rc -ge 124 ] && exit $rc
+Q="--no-cpu-baseline --no-kernel-bench --no-traffic --no-bf16x3"
+for i in 1 2; do timeout -k 10 300 python bench.py $Q > $out/bench_$i.log 2>&1; echo "bench $i: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$i.log | head -1)"; done
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x3 --no-traffic --no-kernel-bench > $GRAFT_REPO_ROOT/$out/stats.log 2>&1; echo "stats rc=$?"
+grep -h "wgq\|snb_" $GRAFT_REPO_ROOT/$out/stats/r_kernel_stats.csv | cut -c1-80
