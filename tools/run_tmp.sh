@@ -1,10 +1,12 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02s; mkdir -p $out
-timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py tests/test_gpu_bf16x3.py -m gpu -q > $out/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc: $(tail -1 $out/pytest.log)"; grep -E "^FAILED|^ERROR" $out/pytest.log | head
-[ $rc -ge 124 ] && exit $rc
-Q="--no-cpu-baseline --no-kernel-bench --no-traffic --no-bf16x3"
-for i in 1 2; do timeout -k 10 300 python bench.py $Q > $out/bench_$i.log 2>&1; echo "bench $i: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$i.log | head -1)"; done
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x3 --no-traffic --no-kernel-bench > $GRAFT_REPO_ROOT/$out/stats.log 2>&1; echo "stats rc=$?"
-grep -h "wgq\|snb_" $GRAFT_REPO_ROOT/$out/stats/r_kernel_stats.csv | cut -c1-80
+out=gpurun_out/r02t; mkdir -p $out
+P="timeout -k 10 120 python tools/kernel_probe.py"
+{
+for lib in "" tools/micro/_exp/libgim_stagger1.so tools/micro/_exp/libgim_stagger3.so; do
+ for shp in "fwd 80 32 64 128 3 0 20 0" "dgrad 80 32 64 128 3 0 20 0" "fwd 160 64 64 64 3 0 20 1" "fwd 80 16 128 256 3 0 20 0" "fwd 80 64 64 64 9 0 10 1" "fwd 320 32 128 128 3 0 10 0"; do
+   GIM_LIB_PATH=$lib $P $shp 2>&1 | grep -v amdgpu.ids | sed "s#^#[${lib:-product}] #" || exit 1
+ done
+done
+} > $out/stagger_probe.txt 2>&1
+cat $out/stagger_probe.txt | cut -c1-60,150-230
