@@ -98,7 +98,7 @@ def _ref_device():
             w = torch.randn(7, 5, 3, 3, dtype=torch.float64, generator=g)
             outs = []
             for d in ("cpu", "cuda:0"):
-                xx, ww = x.to(d).requires_grad_(), w.to(d).requires_grad_()
+                xx, ww = x.detach().clone().to(d).requires_grad_(), w.detach().clone().to(d).requires_grad_()   # fresh leaves per device
                 y = F.avg_pool2d(F.conv2d(F.leaky_relu(xx, 0.2), ww, padding=1), 2)
                 y.square().sum().backward()
                 outs.append([t.detach().cpu() for t in (y, xx.grad, ww.grad)])
