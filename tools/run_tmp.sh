@@ -1,15 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02v; mkdir -p $out
+out=gpurun_out/r02x; mkdir -p $out
+timeout -k 10 600 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; rc=$?
+echo "pytest rc=$rc: $(grep -E 'passed|failed' $out/pytest_gpu.log | tail -1)"; grep -E "^FAILED|^ERROR" $out/pytest_gpu.log | head
+[ $rc -ge 124 ] && exit $rc
+timeout -k 10 300 python tools/conv_shapes_bench.py > $out/conv_shapes_fp32.txt 2>&1; tail -1 $out/conv_shapes_fp32.txt
 Q="--no-cpu-baseline --no-kernel-bench --no-traffic --no-bf16x3"
-run() { # name, env...
-  name=$1; shift
-  env "$@" timeout -k 10 300 python bench.py $Q > $out/bench_$name.log 2>&1
-  echo "$name: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$name.log | head -1) median $(grep -o '"ms_per_step_median": [0-9.]*' $out/bench_$name.log) steps $(grep -o '"per_step_ms": [^]]*]' $out/bench_$name.log | cut -c1-140)"
-}
-run default1 A=1
-run rccl1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29551 GIM_FORCE_ALLREDUCE=1
-run default2 A=1
-run rccl2 MASTER_ADDR=127.0.0.1 MASTER_PORT=29552 GIM_FORCE_ALLREDUCE=1
-run rccl_q4 MASTER_ADDR=127.0.0.1 MASTER_PORT=29553 GIM_FORCE_ALLREDUCE=1 GPU_MAX_HW_QUEUES=4
-run gloo2 GIM_BENCH_BACKEND=gloo GIM_BENCH_ONE_DEVICE=1 X=1
+for i in 1 2; do timeout -k 10 300 python bench.py $Q > $out/bench_$i.log 2>&1; echo "bench $i: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$i.log | head -1)"; done
