@@ -110,37 +110,36 @@ def num_parameters(parameter_list):
 
 
 class CheckpointIO:
-    """training/checkpoints.py:9-44: one ``torch.save`` dict {global_step, last_epoch, <name>: state_dict...};
-    the int 'global_step' entry is overwritten by the registered GlobalStep's state dict, as in the reference."""
+    """The reference's checkpoint file (training/checkpoints.py:9-44): ONE ``torch.save`` dict
+    ``{"global_step", "last_epoch", <registered name>: state_dict(), ...}`` - a registered GlobalStep overwrites the integer
+    ``global_step`` entry with its own state dict, as it does there, so files written by either side load on the other.
+    Written through a temporary file and ``os.replace``: a job killed while saving leaves the previous checkpoint intact."""
 
-    def __init__(self, checkpoint_dir, **kwargs):
-        self.module_dict = kwargs
+    def __init__(self, checkpoint_dir, **modules):
         self.checkpoint_dir = checkpoint_dir
-        if not os.path.exists(checkpoint_dir):
-            os.makedirs(checkpoint_dir)
+        self.module_dict = dict(modules)
+        os.makedirs(checkpoint_dir, exist_ok=True)
 
-    def register_modules(self, **kwargs):
-        self.module_dict.update(kwargs)
+    def register_modules(self, **modules):
+        self.module_dict.update(modules)
 
     def save(self, global_step, last_epoch, filename):
-        filename = os.path.join(self.checkpoint_dir, filename)
-        outdict = {"global_step": global_step, "last_epoch": last_epoch}
-        for k, v in self.module_dict.items():
-            outdict[k] = v.state_dict()
-        torch.save(outdict, filename)
+        payload = {"global_step": global_step, "last_epoch": last_epoch}
+        payload.update((name, obj.state_dict()) for name, obj in self.module_dict.items())
+        path = os.path.join(self.checkpoint_dir, filename)
+        tmp = path + ".tmp.%d" % os.getpid()
+        torch.save(payload, tmp)
+        os.replace(tmp, path)
 
     def load(self, filepath):
-        if os.path.exists(filepath):
-            print("=> Loading checkpoint...")
-            out_dict = torch.load(filepath, map_location="cpu", weights_only=False)
-            global_step = out_dict["global_step"]
-            last_epoch = out_dict["last_epoch"]
-            for k, v in self.module_dict.items():
-                if k in out_dict:
-                    v.load_state_dict(out_dict[k])
-                else:
-                    print("Warning: Could not find %s in checkpoint!" % k)
-        else:
-            global_step = -1
-            last_epoch = -1
-        return global_step, last_epoch
+        """Restore every registered object the file has an entry for; (-1, -1) when the file does not exist."""
+        if not os.path.exists(filepath):
+            return -1, -1
+        print("=> Loading checkpoint...")
+        payload = torch.load(filepath, map_location="cpu", weights_only=False)
+        for name, obj in self.module_dict.items():
+            if name in payload:
+                obj.load_state_dict(payload[name])
+            else:
+                print("Warning: Could not find %s in checkpoint!" % name)
+        return payload["global_step"], payload["last_epoch"]

@@ -789,7 +789,10 @@ def test_two_rank_data_parallel_step_on_gpu(tmp_path):
     bad = []
     for k_ in a["state"]:
         e = relerr(b["state"][k_], a["state"][k_])
-        if e > (5.5e-2 if k_.endswith(".bias") else 5e-3):   # zero-gradient biases random-walk by +-lr (see the overlap test)
+        # zero-gradient biases random-walk by +-lr (see the overlap test); in a few generator conv weights up to ~1e-4 of the
+        # elements have gradients at rounding level, and each such element whose sign differs between the two summation orders
+        # ends 2 * lr apart after an Adam(beta1 = 0) step: observed 3e-3 ... 7e-3 of the tensor's norm over the round's runs
+        if e > (5.5e-2 if k_.endswith(".bias") else 1.5e-2):
             bad.append((k_, e))
     assert not bad, bad[:5]
 
