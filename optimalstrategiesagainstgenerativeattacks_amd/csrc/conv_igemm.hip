@@ -822,8 +822,11 @@ __device__ __forceinline__ void x3_split_store_planes(char* dst, int plane_bytes
     *reinterpret_cast<u32x2*>(dst + 2 * plane_bytes) = lo;
 }
 
-template <int BM, int BN, int TM, int TN, int VA, int VB, bool FASTB, int PREC = 0>
+// WBK: pixels per K step (16; 32 for the 64x64 tile of tile code 6432 - that tile does 8 MFMAs per wave and step, so the per-step
+// costs weigh twice as much as on the larger tiles; 32 KB of LDS, still 4 workgroups per CU).
+template <int BM, int BN, int TM, int TN, int VA, int VB, bool FASTB, int PREC = 0, int WBK = BK>
 __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP p) {
+    static_assert(!(PREC == 1) || WBK == 16, "bf16x3 wgrad: 16-pixel steps only");
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -832,11 +835,11 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     static_assert(!FASTB || VB == 4, "fast B addressing: vector path only");
     constexpr int AU = BM / VA, BU = BN / VB;                   // load units per tile row
     constexpr int A_RSTEP = 256 / AU, B_RSTEP = 256 / BU;       // tile rows covered per pass
-    constexpr int A_PER = (BK + A_RSTEP - 1) / A_RSTEP, B_PER = (BK + B_RSTEP - 1) / B_RSTEP;
+    constexpr int A_PER = (WBK + A_RSTEP - 1) / A_RSTEP, B_PER = (WBK + B_RSTEP - 1) / B_RSTEP;
     // bf16x3 image: bytes per k-row (stride = 64 mod 128), per plane, per buffer
     constexpr int RSA = ((BM * 2) % 128 == 64) ? BM * 2 : BM * 2 + 64, RSB = ((BN * 2) % 128 == 64) ? BN * 2 : BN * 2 + 64;
-    constexpr int PLA = BK * RSA, PLB = BK * RSB;
-    constexpr int A_FLOATS = X3 ? 3 * PLA / 4 : BK * BM, B_FLOATS = X3 ? 3 * PLB / 4 : BK * BN;
+    constexpr int PLA = WBK * RSA, PLB = WBK * RSB;
+    constexpr int A_FLOATS = X3 ? 3 * PLA / 4 : WBK * BM, B_FLOATS = X3 ? 3 * PLB / 4 : WBK * BN;
     static_assert(!X3 || 2 * A_FLOATS >= 256 * VA, "bias reduction scratch");
     __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
@@ -862,13 +865,13 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     const bool do_bias = p.bias_slabs != nullptr && bx == 0;
 
     // ---- vector-path fast addressing (tools/micro/mfma_valu.hip: VALU work is paid in matrix-pipe time) ----
-    // A (dy rows): buffer resource whose BASE advances by BK rows per step and whose num_records shrinks to the rows left
+    // A (dy rows): buffer resource whose BASE advances by WBK rows per step and whose num_records shrinks to the rows left
     //   in this pixel slice: lane offsets are constants and rows beyond the slice read zeros - no per-step VALU at all.
-    // B (gathered x): when the BK pixels of a K step lie in ONE image (H * W % BK == 0, no on-the-fly upsample) pixel `row` of
+    // B (gathered x): when the WBK pixels of a K step lie in ONE image (H * W % WBK == 0, no on-the-fly upsample) pixel `row` of
     //   the step sits at (oy0 + (row >> logW), ox0 + (row & (W - 1))) with (oy0, ox0) wave-uniform, so the element offset is
     //   U(n, oy0, ox0)  [SALU]  +  L(tap, channel, tile row)  [lane constant]; only the zero-padding test is per lane (two adds,
     //   two compares, one select per tile row).  Otherwise (1x1 and 2x2 maps) the generic per-row address path runs.
-    constexpr bool fastb = FASTB;  // host: VB == 4 && ups == 0 && H * W % BK == 0
+    constexpr bool fastb = FASTB;  // host: VB == 4 && ups == 0 && H * W % WBK == 0
     unsigned a_v[A_PER], b_l[B_PER];
     int b_dx[B_PER], b_dy[B_PER];
     // the most negative lane constant is shifted into the base pointer so that every offset is a non-negative 32-bit value
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int row = ak + i * A_RSTEP;
-            a_v[i] = row < BK ? (unsigned)((row * p.Cout + min(co0 + ac, p.Cout - 4)) * 4) : BUF_OOB;
+            a_v[i] = row < WBK ? (unsigned)((row * p.Cout + min(co0 + ac, p.Cout - 4)) * 4) : BUF_OOB;
         }
     }
     if constexpr (VB == 4) {
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
             const int row = bk + i * B_RSTEP;
             b_dy[i] = (row >> g.logW) * g.s_in + dh;
             b_dx[i] = (row & (g.W - 1)) * g.s_in + dw;
-            b_l[i] = (b_jok && row < BK) ? (unsigned)(((b_dy[i] * g.Win + b_dx[i]) * p.Cin + ci) * 4 + b_bias) : BUF_OOB;
+            b_l[i] = (b_jok && row < WBK) ? (unsigned)(((b_dy[i] * g.Win + b_dx[i]) * p.Cin + ci) * 4 + b_bias) : BUF_OOB;
         }
     }
 
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         if constexpr (VA == 4) {
             const int left = mend - mb;  // > 0
             const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(p.dy + (long long)mb * p.Cout), 0, (unsigned)min(left, BK) * (unsigned)p.Cout * 4u, 0x00020000);
+                (void*)(p.dy + (long long)mb * p.Cout), 0, (unsigned)min(left, WBK) * (unsigned)p.Cout * 4u, 0x00020000);
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const f32x4 val = buf_load4(ra_rs, a_v[i], 0);
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
             for (int i = 0; i < A_PER; ++i) {
                 const int row = ak + i * A_RSTEP;
                 const int m = mb + row;
-                const bool v = a_cok && row < BK && m < mend;
+                const bool v = a_cok && row < WBK && m < mend;
                 ra[i][0] = v ? p.dy[(long long)m * p.Cout + co0 + ac] : 0.f;
             }
         }
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
                     const int n = m >> (g.logH + g.logW);
                     const int iy = ((m >> g.logW) & (g.H - 1)) * g.s_in + dh;
                     const int ix = (m & (g.W - 1)) * g.s_in + dw;
-                    const bool v = b_jok && row < BK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
+                    const bool v = b_jok && row < WBK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
                     const unsigned off = (unsigned)((((n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci) * 4 + b_bias);
                     const f32x4 val = buf_load4(rxb, v ? off : BUF_OOB, 0);
 #pragma unroll
@@ -955,7 +958,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
                 const int n = m >> (g.logH + g.logW);
                 const int iy = ((m >> g.logW) & (g.H - 1)) * g.s_in + dh;
                 const int ix = (m & (g.W - 1)) * g.s_in + dw;
-                const bool v = b_jok && row < BK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
+                const bool v = b_jok && row < WBK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
                 const long long off = ((long long)(n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci;
                 rb[i][0] = v ? p.x[off] : 0.f;
             }
@@ -988,19 +991,19 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const int row = ak + i * A_RSTEP;
-                if (A_RSTEP * A_PER == BK || row < BK) x3_split_store_planes(reinterpret_cast<char*>(&As[buf][0]) + row * RSA + ac * 2, PLA, ra[i]);
+                if (A_RSTEP * A_PER == WBK || row < WBK) x3_split_store_planes(reinterpret_cast<char*>(&As[buf][0]) + row * RSA + ac * 2, PLA, ra[i]);
             }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
                 const int row = bk + i * B_RSTEP;
-                if (B_RSTEP * B_PER == BK || row < BK) x3_split_store_planes(reinterpret_cast<char*>(&Bs[buf][0]) + row * RSB + bc * 2, PLB, rb[i]);
+                if (B_RSTEP * B_PER == WBK || row < WBK) x3_split_store_planes(reinterpret_cast<char*>(&Bs[buf][0]) + row * RSB + bc * 2, PLB, rb[i]);
             }
             return;
         }
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int row = ak + i * A_RSTEP;
-            if (row < BK) {
+            if (row < WBK) {
                 if constexpr (VA == 4) {
                     f32x4 val = {ra[i][0], ra[i][1], ra[i][2], ra[i][3]};
                     *reinterpret_cast<f32x4*>(&As[buf][row * BM + ac]) = val;
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int row = bk + i * B_RSTEP;
-            if (row < BK) {
+            if (row < WBK) {
                 if constexpr (VB == 4) {
                     f32x4 val = {rb[i][0], rb[i][1], rb[i][2], rb[i][3]};
                     *reinterpret_cast<f32x4*>(&Bs[buf][row * BN + bc]) = val;
@@ -1046,14 +1049,14 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     const int tr_a = (8 * h + tr_q) * RSA + (wm0 + 16 * tr_g + 4 * tr_p) * 2;
     const int tr_b = (8 * h + tr_q) * RSB + (wn0 + 16 * tr_g + 4 * tr_p) * 2;
 
-    const int nk = (mend > mbeg) ? (mend - mbeg + BK - 1) / BK : 0;
+    const int nk = (mend > mbeg) ? (mend - mbeg + WBK - 1) / WBK : 0;
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, NSET - 1>;
     if (nk > 0) {
         load_tiles(mbeg, Set0());
         store_tiles(0, Set0());
         if constexpr (X3) {
-            if (nk > 1) load_tiles(mbeg + BK, Set1());
+            if (nk > 1) load_tiles(mbeg + WBK, Set1());
         }
     }
     __syncthreads();
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         auto kstep = [&](int ks, auto BUFC, auto MAINC) {
             constexpr int buf = decltype(BUFC)::value;
             constexpr bool MAIN = decltype(MAINC)::value;
-            if (MAIN || ks + 2 < nk) load_tiles(mbeg + (ks + 2) * BK, std::integral_constant<int, buf>());
+            if (MAIN || ks + 2 < nk) load_tiles(mbeg + (ks + 2) * WBK, std::integral_constant<int, buf>());
             __builtin_amdgcn_sched_barrier(0);
             mma(buf);
             __builtin_amdgcn_sched_barrier(0);
@@ -1107,10 +1110,10 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     const float* b_rd = &Bs[0][0] + h * BN + wn0 + r;
     auto kstep32 = [&](int ks, auto BUFC) {
         constexpr int buf = decltype(BUFC)::value;
-        if (ks + 1 < nk) load_tiles(mbeg + (ks + 1) * BK, Set0());
+        if (ks + 1 < nk) load_tiles(mbeg + (ks + 1) * WBK, Set0());
         __builtin_amdgcn_sched_barrier(0);  // keep every consumer of the staged registers behind the MFMA block
 #pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
+        for (int kp = 0; kp < WBK / 2; ++kp) {
             float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = a_rd[buf * A_FLOATS + 2 * kp * BM + 32 * i];
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         }
 
     if (do_bias) {  // block-uniform; As is free after the loop's last barrier
-        float* red = &As[0][0];  // needs (256 / AU) * BM = 256 * VA <= 2 * BK * BM floats
+        float* red = &As[0][0];  // needs (256 / AU) * BM = 256 * VA <= 2 * WBK * BM floats
 #pragma unroll
         for (int e = 0; e < VA; ++e) red[ak * BM + ac + e] = bsum[e];
         __syncthreads();
@@ -1521,7 +1524,7 @@ extern "C" int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float*
 // stride 2 over the (K+1)^2 folded taps -> slabs in F layout [Cout][KF][KF][Cin].  sub-pixel (ups + wfold), roles
 // swapped: A = leaky_relu(x) [N,H/2,W/2,Cin], B = dy [N,H,W,Cout] gathered with stride 2 -> slabs
 // G[Cin][KF][KF][Cout] with G[ci][ta][tb][co] = dF[co][K-ta][K-tb][ci] (gim_wgrad_finish un-transposes).
-struct WgPlan { int bm, bn, ns, mper, rows, cols, M, table_hit; };
+struct WgPlan { int bm, bn, ns, mper, rows, cols, M, table_hit, bk; };
 
 static WgPlan wgrad_plan(const gim_conv_shape* s) {
     WgPlan q{};
@@ -1545,8 +1548,10 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     if (tile == 128) { q.bm = 128; q.bn = 128; }
     else if (tile == 641) { q.bm = 64; q.bn = 128; }
     else if (tile == 1264) { q.bm = 128; q.bn = 64; }
-    else if (tile == 64) { q.bm = 64; q.bn = 64; }
+    else if (tile == 64 || tile == 6432) { q.bm = 64; q.bn = 64; }
     else if (tile == 32128) { q.bm = 32; q.bn = 128; }
+    // 32-pixel K steps: fp32 path, both operands on 16-byte loads (the launcher falls back to 16 otherwise)
+    q.bk = (tile == 6432 && s->prec == 0 && q.rows % 4 == 0 && (up_fold ? s->Cout : s->Cin) % 4 == 0) ? 32 : BK;
     const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
     // Heuristic: about four workgroups per CU in total and at least 32 K-steps (512 pixels) per workgroup, so that the float
     // atomics of the combine stay small next to the MFMA work - unless that leaves most CUs idle (1x1 convs and linears on small
@@ -1566,7 +1571,7 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     if (S > 1024) S = 1024;
     if (S < 1) S = 1;
     long long mp = (M + S - 1) / S;
-    mp = (mp + BK - 1) / BK * BK;
+    mp = (mp + q.bk - 1) / q.bk * q.bk;
     q.mper = (int)mp;
     q.ns = (int)((M + mp - 1) / mp);
     return q;
@@ -1591,7 +1596,13 @@ static void launch_wgrad_x3(const WgP& p, int bm, int bn, dim3 g, hipStream_t st
 }
 
 template <int VA, int VB, bool FASTB>
-static void launch_wgrad(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
+static void launch_wgrad(const WgP& p, int bm, int bn, int bk, dim3 g, hipStream_t st) {
+    if constexpr (VA == 4 && VB == 4) {
+        if (bk == 32 && bm == 64 && bn == 64) {
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, 4, 4, FASTB, 0, 32>), g, dim3(256), 0, st, p);
+            return;
+        }
+    }
     if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, VA, VB, FASTB>), g, dim3(256), 0, st, p);
     else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, VA, VB, FASTB>), g, dim3(256), 0, st, p);
     else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, VA, VB, FASTB>), g, dim3(256), 0, st, p);
@@ -1645,17 +1656,18 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     // per operand as the kernel sees it (the sub-pixel form swaps the roles): A = p.dy with p.Cout channels, B = p.x with p.Cin
     const bool va = (p.Cout % 4 == 0) && !((uintptr_t)p.dy & 15);
     const bool vb = (p.Cin % 4 == 0) && !((uintptr_t)p.x & 15);
-    const bool fastb = vb && p.g.ups == 0 && ((p.g.H * p.g.W) & (BK - 1)) == 0;   // a K step stays inside one image
+    const int bk = (q.bk == 32 && va && vb && s->prec == 0) ? 32 : BK;
+    const bool fastb = vb && p.g.ups == 0 && ((p.g.H * p.g.W) & (bk - 1)) == 0;   // a K step stays inside one image
     hipStream_t st = (hipStream_t)stream;
     if (s->prec == 1 && va && vb) {
         if (fastb) launch_wgrad_x3<true>(p, q.bm, q.bn, g, st);
         else launch_wgrad_x3<false>(p, q.bm, q.bn, g, st);
     }
-    else if (va && fastb) launch_wgrad<4, 4, true>(p, q.bm, q.bn, g, st);
-    else if (va && vb) launch_wgrad<4, 4, false>(p, q.bm, q.bn, g, st);
-    else if (va) launch_wgrad<4, 1, false>(p, q.bm, q.bn, g, st);
-    else if (vb) launch_wgrad<1, 4, false>(p, q.bm, q.bn, g, st);
-    else launch_wgrad<1, 1, false>(p, q.bm, q.bn, g, st);
+    else if (va && fastb) launch_wgrad<4, 4, true>(p, q.bm, q.bn, bk, g, st);
+    else if (va && vb) launch_wgrad<4, 4, false>(p, q.bm, q.bn, bk, g, st);
+    else if (va) launch_wgrad<4, 1, false>(p, q.bm, q.bn, bk, g, st);
+    else if (vb) launch_wgrad<1, 4, false>(p, q.bm, q.bn, bk, g, st);
+    else launch_wgrad<1, 1, false>(p, q.bm, q.bn, bk, g, st);
     return gim_check_launch("gim_conv2d_wgrad");
 }
 

@@ -124,7 +124,7 @@ def main():
             t_auto = time_ms(lambda: fn(sh))
             best = (t_auto, 0, 0)
             if kind == "wgrad":   # output tile x workgroup target of the pixel slicing (an explicit target lifts the 512-pixel floor)
-                cands = [(tl, 0, tg) for tl in (0, 128, 641, 1264, 64) for tg in (128, 256, 512, 1024, 2048, 4096, 8192)]
+                cands = [(tl, 0, tg) for tl in (0, 128, 641, 1264, 64) + (() if x3 else (6432,)) for tg in (128, 256, 512, 1024, 2048, 4096, 8192)]
             else:
                 tiles = [128, 641, 1264, 64] if Cb > 64 else ([1264, 64] if Cb > 32 else [])
                 if tiles and not x3 and keys[kind][2] % 32 == 0:
