@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         if constexpr (X3) {
             if (MAIN || ks + 2 < nk) load_tiles((ks + 2) * KB, std::integral_constant<int, buf>());   // this set's step was stored before the last barrier
         } else {
-            if (ks + 1 < nk) load_tiles((ks + 1) * KB, Set0());
+            if (MAIN || ks + 1 < nk) load_tiles((ks + 1) * KB, Set0());
         }
         __builtin_amdgcn_sched_barrier(0);  // nothing that touches the staged registers may move into the MFMA block
         const float* Ab = As + buf * A_SZ;
@@ -671,6 +671,12 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
     int ks = ks0;
     if constexpr (X3) {
         for (; ks + 3 < nk; ks += 2) {   // steady state: steps ks and ks+1 both have a step two ahead to load
+            kstep(ks, std::integral_constant<int, 0>(), std::true_type());
+            kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
+        }
+    }
+    if constexpr (!X3) {
+        for (; ks + 2 < nk; ks += 2) {   // steady state: both steps have a successor to load - no conditions around the loads / stores
             kstep(ks, std::integral_constant<int, 0>(), std::true_type());
             kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
         }
