@@ -1114,9 +1114,10 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     // immediates instead of costing address VALU next to the MFMAs (every VALU instruction is paid in matrix-pipe time)
     const float* a_rd = &As[0][0] + h * BM + wm0 + r;
     const float* b_rd = &Bs[0][0] + h * BN + wn0 + r;
-    auto kstep32 = [&](int ks, auto BUFC) {
+    auto kstep32 = [&](int ks, auto BUFC, auto MAINC) {
         constexpr int buf = decltype(BUFC)::value;
-        if (ks + 1 < nk) load_tiles(mbeg + (ks + 1) * WBK, Set0());
+        constexpr bool MAIN = decltype(MAINC)::value;   // a step of the steady-state loop: it has a successor, loads / stores unconditional
+        if (MAIN || ks + 1 < nk) load_tiles(mbeg + (ks + 1) * WBK, Set0());
         __builtin_amdgcn_sched_barrier(0);  // keep every consumer of the staged registers behind the MFMA block
 #pragma unroll
         for (int kp = 0; kp < WBK / 2; ++kp) {
@@ -1132,15 +1133,19 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 1 < nk) store_tiles(buf ^ 1, Set0());
+        if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1, Set0());
         __syncthreads();
     };
     int ks = 0;
-    for (; ks + 1 < nk; ks += 2) {   // whole pairs: no control flow between the two steps (a branch there makes the compiler carry
-        kstep32(ks, std::integral_constant<int, 0>());       // the accumulators in VGPRs and copy them to AGPRs every trip)
-        kstep32(ks + 1, std::integral_constant<int, 1>());
+    for (; ks + 2 < nk; ks += 2) {   // steady state: whole pairs, every step has a successor
+        kstep32(ks, std::integral_constant<int, 0>(), std::true_type());
+        kstep32(ks + 1, std::integral_constant<int, 1>(), std::true_type());
     }
-    if (ks < nk) kstep32(ks, std::integral_constant<int, 0>());
+    for (; ks + 1 < nk; ks += 2) {   // whole pairs: no control flow between the two steps (a branch there makes the compiler carry
+        kstep32(ks, std::integral_constant<int, 0>(), std::false_type());       // the accumulators in VGPRs and copy them to AGPRs every trip)
+        kstep32(ks + 1, std::integral_constant<int, 1>(), std::false_type());
+    }
+    if (ks < nk) kstep32(ks, std::integral_constant<int, 0>(), std::false_type());
     }
 
     if constexpr (X3) {
