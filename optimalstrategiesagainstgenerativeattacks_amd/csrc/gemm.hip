@@ -89,6 +89,93 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgP p) {
     }
 }
 
+// Vector form of the same product for operands whose unit-stride extent is a multiple of 4 and 16-byte aligned (every
+// SelfAttention product of the benchmark shapes): one 16-byte global load per thread, operand and 16 K values instead of four
+// scalar loads with 64-bit address arithmetic each, K step 32 (16 MFMAs per wave between barriers instead of 8), LDS rows of 68
+// floats (16-byte aligned rows for the b128 stores of an m- / n-contiguous operand; the four scalar stores of a k-contiguous
+// one and the scalar operand reads stay conflict-free per half-wave).  AK / BK: the operand's unit stride is along K.
+#define GLV 68
+#define GKV 32
+template <bool AK, bool BK_>
+__global__ __launch_bounds__(256) void bgemm_vec_kernel(const BgP p) {
+    __shared__ __attribute__((aligned(16))) float As[2][GKV * GLV];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GKV * GLV];
+    const int t = threadIdx.x;
+    const int i0 = blockIdx.y * GB, j0 = blockIdx.x * GB;
+    const float* A = p.A + (long long)blockIdx.z * p.sAb;
+    const float* B = p.B + (long long)blockIdx.z * p.sBb;
+    // per-thread element of each 16-byte load.  k-contiguous operand: row = t >> 3 (+32), k quad = t & 7;
+    // m- / n-contiguous operand: k row = t >> 4 (+16), column quad = t & 15
+    f32x4 ra[2], rb[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if constexpr (AK) {
+                const int i = i0 + (t >> 3) + 32 * e, k = k0 + 4 * (t & 7);
+                ra[e] = (i < p.M && k < p.K) ? *reinterpret_cast<const f32x4*>(A + (long long)i * p.sAi + k) : zero4;
+            } else {
+                const int k = k0 + (t >> 4) + 16 * e, i = i0 + 4 * (t & 15);
+                ra[e] = (i < p.M && k < p.K) ? *reinterpret_cast<const f32x4*>(A + (long long)k * p.sAk + i) : zero4;
+            }
+            if constexpr (BK_) {
+                const int j = j0 + (t >> 3) + 32 * e, k = k0 + 4 * (t & 7);
+                rb[e] = (j < p.N && k < p.K) ? *reinterpret_cast<const f32x4*>(B + (long long)j * p.sBj + k) : zero4;
+            } else {
+                const int k = k0 + (t >> 4) + 16 * e, j = j0 + 4 * (t & 15);
+                rb[e] = (j < p.N && k < p.K) ? *reinterpret_cast<const f32x4*>(B + (long long)k * p.sBk + j) : zero4;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if constexpr (AK) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[buf][(4 * (t & 7) + q) * GLV + (t >> 3) + 32 * e] = ra[e][q];
+            } else {
+                *reinterpret_cast<f32x4*>(&As[buf][((t >> 4) + 16 * e) * GLV + 4 * (t & 15)]) = ra[e];
+            }
+            if constexpr (BK_) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Bs[buf][(4 * (t & 7) + q) * GLV + (t >> 3) + 32 * e] = rb[e][q];
+            } else {
+                *reinterpret_cast<f32x4*>(&Bs[buf][((t >> 4) + 16 * e) * GLV + 4 * (t & 15)]) = rb[e];
+            }
+        }
+    };
+    const int lane = t & 63, r = lane & 31, h = lane >> 5, wv = t >> 6;
+    const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int nk = (p.K + GKV - 1) / GKV;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_tiles((ks + 1) * GKV);
+#pragma unroll
+        for (int kp = 0; kp < GKV / 2; ++kp) {
+            const float a = As[buf][(2 * kp + h) * GLV + wm0 + r];
+            const float b = Bs[buf][(2 * kp + h) * GLV + wn0 + r];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (ks + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    float* C = p.C + (long long)blockIdx.z * p.M * p.N;
+    const int j = j0 + wn0 + r;
+    if (j < p.N) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (i < p.M) C[(long long)i * p.N + j] = acc[e];
+        }
+    }
+}
+
 extern "C" int gim_bgemm(const float* A, const float* B, float* C, int batch, int M, int N, int K, int64_t sAb, int64_t sAi,
                          int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, void* stream) {
     GIM_CHECK_ARG(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0, "bgemm: bad args");
@@ -97,6 +184,20 @@ extern "C" int gim_bgemm(const float* A, const float* B, float* C, int batch, in
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
     p.sAb = sAb; p.sAi = sAi; p.sAk = sAk; p.sBb = sBb; p.sBk = sBk; p.sBj = sBj;
     dim3 g((N + GB - 1) / GB, (M + GB - 1) / GB, batch);
-    hipLaunchKernelGGL(bgemm_kernel, g, dim3(256), 0, (hipStream_t)stream, p);
+    // vector path: each operand's unit-stride extent (K for a k-contiguous operand, M / N otherwise) is a multiple of 4, its
+    // other strides too, and the base pointers are 16-byte aligned - then every 16-byte load is aligned and never straddles a tile edge
+    const bool ak = sAk == 1, bk = sBk == 1;
+    const bool va = ak ? (K % 4 == 0 && sAi % 4 == 0) : (sAi == 1 && M % 4 == 0 && sAk % 4 == 0);
+    const bool vb = bk ? (K % 4 == 0 && sBj % 4 == 0) : (sBj == 1 && N % 4 == 0 && sBk % 4 == 0);
+    const bool al = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && sAb % 4 == 0 && sBb % 4 == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (va && vb && al) {
+        if (ak && bk) hipLaunchKernelGGL((bgemm_vec_kernel<true, true>), g, dim3(256), 0, st, p);
+        else if (ak) hipLaunchKernelGGL((bgemm_vec_kernel<true, false>), g, dim3(256), 0, st, p);
+        else if (bk) hipLaunchKernelGGL((bgemm_vec_kernel<false, true>), g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((bgemm_vec_kernel<false, false>), g, dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(bgemm_kernel, g, dim3(256), 0, st, p);
+    }
     return gim_check_launch("gim_bgemm");
 }
