@@ -641,28 +641,35 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
                         if (q < 5) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[j][TB[q]], acc2[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[j][TB[q]], acc[i][j], 0, 0, 0);
                     }
-        } else
+        } else {
+            // all operand fragments of the K step first, in registers of their own (with per-group arrays the compiler re-used the
+            // same registers for the second half of a 32-deep step and could issue its LDS reads only after the first 8 MFMAs)
+            f32x4 a[KB / 8][TM], b[KB / 8][TN];
 #pragma unroll
-        for (int kk = 0; kk < KB / 8; ++kk) {
-            f32x4 a[TM], b[TN];
+            for (int kk = 0; kk < KB / 8; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + 32 * i + r) * LDK + 8 * kk + 4 * h]);
+                for (int i = 0; i < TM; ++i) a[kk][i] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + 32 * i + r) * LDK + 8 * kk + 4 * h]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (BMODE == 0) {
-                    b[j] = *reinterpret_cast<const f32x4*>(&Bb[(wn0 + 32 * j + r) * LDK + 8 * kk + 4 * h]);
-                } else {
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (BMODE == 0) {
+                        b[kk][j] = *reinterpret_cast<const f32x4*>(&Bb[(wn0 + 32 * j + r) * LDK + 8 * kk + 4 * h]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[j][e] = Bb[(8 * kk + 4 * h + e) * BN + wn0 + 32 * j + r];
+                        for (int e = 0; e < 4; ++e) b[kk][j][e] = Bb[(8 * kk + 4 * h + e) * BN + wn0 + 32 * j + r];
+                    }
                 }
             }
+            // (128x128 tiles hold 64 accumulators per lane: there the barrier would cost spills, the compiler interleaves as before)
+            if constexpr (TM * TN <= 2) __builtin_amdgcn_sched_barrier(0);   // keep the reads in front: the MFMA block below waits for them in order
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int kk = 0; kk < KB / 8; ++kk)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i][e], b[kk][j][e], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1, std::integral_constant<int, X3 ? (buf ^ 1) : 0>());
