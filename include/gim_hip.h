@@ -60,7 +60,12 @@ int gim_version(void);
  *             the summation order.
  *   out_zeroed = 1: (gim_conv2d_fwd / _dgrad / _dgrad_t) the caller guarantees that the output buffer holds zeros.  Launches that
  *             split K over the grid combine their slices with float atomics and otherwise clear the output themselves (one
- *             memset per launch); a caller that hands out outputs from a zero-filled pool saves those launches. */
+ *             memset per launch); a caller that hands out outputs from a zero-filled pool saves those launches.
+ *   post_slope : (gim_conv2d_fwd only; 0 or 1 = none) LeakyReLU with this slope on the STORED output, y = lrelu(conv + bias +
+ *             residual): the LeakyReLU that the reference applies in front of the NEXT conv (models/model_blocks.py:507), done
+ *             once per element here instead of once per tap and output tile in that conv's K loop (which the caller then runs
+ *             with pre_slope = 1; its dgrad keeps the real slope: the sign of an activated value is the sign of the raw one).
+ *             Refused (GIM_E_BADARG) when the launch splits K - slices combine by addition; ask gim_conv_launch_plan first. */
 typedef struct {
     int32_t N, H, W, Cin, Cout, KH, ups;
     float pre_slope;
@@ -68,6 +73,7 @@ typedef struct {
     int32_t prec;
     int32_t tune_tile, tune_ksplit, tune_wgrad;
     int32_t out_zeroed;
+    float post_slope;
 } gim_conv_shape;
 
 /* F[co][a][b][ci] = sum_{dh,dw in {0,1}} w[co][a-dh][b-dw][ci], a, b in [0, KH]  (out-of-range taps are zero). */

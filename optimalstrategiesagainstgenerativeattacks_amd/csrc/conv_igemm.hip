@@ -90,6 +90,7 @@ struct ConvP {
     int tune_kind;      // host only: row kind of the launch-tuning table (0 fwd, 1 dgrad k-major, 3 fwd bf16x3, 4 dgrad on transposed weights)
     float pos_inf;      // +infinity as a run-time value
     float pre_slope, mask_slope, out_scale;
+    float post_slope;   // forward: leaky-relu on the stored output (1 = none; never with split-K: the slices are combined by addition)
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
     int kper;     // K-steps per slice
@@ -172,7 +173,7 @@ __device__ __forceinline__ void x3_split_store(unsigned* dst, const f32x4& x) {
 // dropped by the lane offset), and nothing in the element loops branches.
 struct EpiCtx {
     __amdgpu_buffer_rsrc_t ry, rr, rm;
-    float scale, mask_slope;
+    float scale, mask_slope, post_slope;
     int M, Cb, logH, logW, Hm1, Wm1, os, py, px, Ho, Wo;
     bool atom, remap;
 };
@@ -239,6 +240,7 @@ __device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE],
             v[q] = a[e0 + q] * c.scale + bv;
             if constexpr (MODE == 1 || MODE == 2) v[q] += ld[q];
             if constexpr (MODE == 3) v[q] *= (ld[q] > 0.f ? 1.0f : c.mask_slope);
+            if constexpr (MODE != 3) v[q] = fmaxf(v[q], v[q] * c.post_slope);   // post_slope = 1: identity (0 < slope <= 1)
         }
         if (c.atom) {
 #pragma unroll
@@ -703,6 +705,7 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
     EpiCtx ec;
     ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
     ec.mask_slope = p.mask_slope;
+    ec.post_slope = p.post_slope;
     const bool first = kslice == 0;
     const bool has_res = p.res != nullptr && first, has_mask = p.mask_x != nullptr;   // block-uniform
     ec.atom = p.ksplit > 1;
@@ -1349,6 +1352,8 @@ static int plan_ksplit(long long wgs, int nk, int tile_area, int want_ks) {
 // gim_conv_launch_plan: when this thread-local pointer is set, the launchers below record what they WOULD launch
 // ({table row found, BM, BN, split-K | wgrad slices, grid x, y, z, matrix path}) and launch nothing.
 static thread_local int32_t* t_plan_out = nullptr;
+// an argument error found only once the launch configuration is known (set by the launcher, returned by the entry point)
+static thread_local bool t_launch_refused = false;
 
 template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int PREC = 0, int KB = 16>
 static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st, bool table_hit) {
@@ -1361,6 +1366,11 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st, bool table_hi
     if (t_plan_out) {
         const int32_t v[8] = {table_hit ? 1 : 0, BM, BN, p.ksplit, gx, gy, p.ksplit * ncls, PREC};
         for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
+        return;
+    }
+    if (p.ksplit > 1 && p.post_slope != 1.f) {   // the K slices are combined by addition: no nonlinearity behind them
+        gim_set_error("conv fwd: post_slope with a launch that splits K (ask gim_conv_launch_plan first)");
+        t_launch_refused = true;
         return;
     }
     if (p.ksplit > 1 && !p.y_zeroed) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
@@ -1459,14 +1469,18 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
         p.x_bytes = (unsigned)xb;
     }
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
+    GIM_CHECK_ARG(s->post_slope >= 0.f && s->post_slope <= 1.f, "conv fwd: post_slope must be in [0, 1] (0 or 1 = none)");
+    p.post_slope = (s->post_slope > 0.f) ? s->post_slope : 1.f;
     p.prec = s->prec;
     p.tune_kind = s->prec == 1 ? 3 : 0;
     p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit; p.y_zeroed = s->out_zeroed;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
+    t_launch_refused = false;
     if (gen) launch_igemm<0, 1>(p, y_elems, (hipStream_t)stream);
     else launch_igemm<0, 0>(p, y_elems, (hipStream_t)stream);
+    if (t_launch_refused) return GIM_E_BADARG;
     if (t_plan_out) return GIM_OK;
     return gim_check_launch("gim_conv2d_fwd");
 }
@@ -1505,6 +1519,7 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
         p.x_bytes = (unsigned)xb;
     }
     p.pre_slope = 1.f; p.mask_slope = s->pre_slope; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = 0;
+    p.post_slope = 1.f;
     const size_t y_elems = (size_t)s->N * (s->H >> (up_fold ? 1 : 0)) * (s->W >> (up_fold ? 1 : 0)) * s->Cin;
     GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cout % BK) != 0 || ((uintptr_t)dy & 15);

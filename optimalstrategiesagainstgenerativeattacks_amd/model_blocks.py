@@ -131,14 +131,17 @@ class SNConv2d(nn.Module):
             self._fold_cache[1].record_stream(cur)   # F was allocated on another stream: keep its memory until this one is done with it
         return self._fold_cache[1]
 
-    def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False):
+    def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, post_slope=1.0, x_act=False):
+        """post_slope != 1: returns (y, activated) - see ops.conv2d_post_act; x_act: x was stored activated by such a producer."""
         guard = None
         if self._sn_queue:
             sigma, u_s, v_s, guard = self._sn_queue.popleft()
         else:
             sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
         wf = self.folded() if (pool or (ups and self.kernel_size > 1)) else None
-        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard)
+        if post_slope != 1.0:
+            return ops.conv2d_post_act(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope)
+        return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, x_act)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d (spectral norm)" % (self.in_channels, self.out_channels, self.kernel_size)
@@ -269,8 +272,11 @@ class ResBlockDown(nn.Module):
 
     def forward(self, x):
         left = self.conv_l1(ops.avg_pool2(x))
-        out = self.conv_r1(x, pre_slope=LRELU)
-        return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True)
+        # conv_r2 is the only reader of conv_r1's output and applies LeakyReLU to it: conv_r1 stores it activated (once per element
+        # in its epilogue) and conv_r2 skips the activation it would otherwise redo for every tap and output tile in its K loop
+        # (-5 ... -10 % of that kernel, profiles/r02_aj_preactivation_cost.txt); launches that split K hand back the raw tensor
+        out, act = self.conv_r1(x, pre_slope=LRELU, post_slope=LRELU)
+        return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True, x_act=act)
 
 
 class SelfAttention(nn.Module):

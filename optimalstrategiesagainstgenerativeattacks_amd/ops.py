@@ -420,7 +420,7 @@ class ConvFn(Function):
     res_ups: the residual is stored at half the output resolution."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf=None, guard=None):
+    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf=None, guard=None, post_slope=1.0, x_act=False):
         lib = _lib.load()
         x = _req(x, "x")
         wp = weight_phys(_req_w(w))
@@ -434,9 +434,17 @@ class ConvFn(Function):
             raise RuntimeError("conv: weight expects %d input channels, got %d" % (w.shape[1], Cin))
         H, W = Hs << ups, Ws << ups
         fold = 1 if (pool or (ups and KH > 1)) else 0
-        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
+        # x_act: x is stored ACTIVATED (its producer applied this conv's LeakyReLU in its epilogue, post_slope below): forward and
+        # wgrad then run without the per-tap activation; dgrad keeps the slope - its mask only needs the sign, which is the same
+        sh = _shape(N, H, W, Cin, Cout, KH, ups, 1.0 if x_act else pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
         Ho, Wo = (H >> 1, W >> 1) if pool else (H, W)
-        y = _conv_out(sh, 0, (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold), (N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), x.device)
+        key = (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold)
+        # post_slope: store lrelu(y) for a consumer that is the ONLY reader of y and runs with x_act (conv2d_post_act decides);
+        # impossible when the launch splits K (the slices combine by addition)
+        _POST_APPLIED[0] = _ACT_STORAGE and post_slope != 1.0 and x.dim() == 4 and not _splits_k(sh, 0, key)
+        if _POST_APPLIED[0]:
+            sh.post_slope = post_slope
+        y = _conv_out(sh, 0, key, (N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), x.device)
         if res is not None:
             res = _req(res, "res")
         if fold and wf is None:
@@ -446,6 +454,7 @@ class ConvFn(Function):
         ctx.save_for_backward(x, w, sigma, u_s, v_s, wf if fold else None, bias)
         ctx.cfg = (N, H, W, Cin, Cout, KH, ups, pre_slope, bias is not None, res is not None, bool(pool), fold, bool(res_ups))
         ctx.guard = guard
+        ctx.x_act = bool(x_act)
         if _FLOPS is not None:
             _note_conv("fwd", ctx.cfg)
         return y
@@ -463,7 +472,7 @@ class ConvFn(Function):
             if ups or res_ups:
                 raise NotImplementedError("second-order backward of an upsampling convolution is not on the R1 path")
             dx = ConvDgradFn.apply(dy, w, x, sigma, u_s, v_s, wf, ctx.cfg) if ctx.needs_input_grad[0] else None
-            return dx, None, None, (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None, None, None, None, None, None
+            return dx, None, None, (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None, None, None, None, None, None, None, None
         wp = weight_phys(w)
         sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
         st = _stream()
@@ -475,7 +484,10 @@ class ConvFn(Function):
         want_b = has_bias and ctx.needs_input_grad[2]
         Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
         if want_w:
-            dw, db = _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, ctx.cfg, want_b, st)
+            sh_w = sh
+            if ctx.x_act:   # the stored x is already lrelu(x): no activation on the wgrad operand
+                sh_w = _shape(N, H, W, Cin, Cout, KH, ups, 1.0, 1 if pool else 0, fold, 1 if res_ups else 0)
+            dw, db = _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh_w, ctx.cfg, want_b, st)
         elif want_b:
             db = torch.empty(Cout, device=dev, dtype=torch.float32)
             scratch = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
@@ -486,9 +498,11 @@ class ConvFn(Function):
                 check(lib.gim_upsample2x_bwd(_p(dy), None, 1.0, _p(dres), N, H >> 1, W >> 1, Cout, st), "upsample2x_bwd")
             else:
                 dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
+_POST_APPLIED = [False]   # did the last ConvFn.forward store its output activated?  (read by conv2d_post_act right after the call)
+_ACT_STORAGE = os.environ.get("GIM_NO_ACT_STORAGE") is None   # A/B switch (host side)
 _NARROW_DGRAD_T = os.environ.get("GIM_NO_NARROW_DGRAD_T") is None   # A/B switch (host side)
 _WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
 
@@ -673,8 +687,18 @@ def _req_w(w):
 
 
 def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, wf=None,
-           guard=None):
-    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard)
+           guard=None, x_act=False):
+    return ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, 1.0, x_act)
+
+
+def conv2d_post_act(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, wf=None,
+                    guard=None, post_slope=1.0):
+    """conv2d whose output may be stored ACTIVATED, y_stored = lrelu(y, post_slope), for a consumer conv that is the only reader
+    of y and is then called with x_act=True (it skips its per-tap LeakyReLU in forward and wgrad; its dgrad masks by the sign,
+    which activation does not change, and hands back the gradient w.r.t. the RAW y - so this conv's backward is unchanged).
+    Returns (y_stored, activated): launches that split K cannot activate (their slices combine by addition) and return raw y."""
+    y = ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope, False)
+    return y, _POST_APPLIED[0]
 
 
 def linear(x, w, bias=None, pre_slope=1.0):

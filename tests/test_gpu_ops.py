@@ -139,6 +139,39 @@ def test_conv2d_pool_fold(case):
         assert relerr(nchw(rg.grad), res.grad) < TOL, "dres"
 
 
+@pytest.mark.parametrize("N,C1,C2,H,expect_act", [(6, 16, 64, 32, True), (2, 64, 64, 4, False)])
+def test_conv_pair_with_activated_storage(N, C1, C2, H, expect_act):
+    """conv_r1 -> LeakyReLU -> pooled conv_r2 (models/model_blocks.py:505-510) with the intermediate stored ACTIVATED by conv_r1's
+    epilogue (ops.conv2d_post_act) and conv_r2 run with x_act: outputs and ALL gradients against fp64 autograd of the unfused
+    form, in both regimes - a launch that can activate in its epilogue and a split-K launch that hands back the raw tensor."""
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
+    tag = "actpair%d_%d_%d_%d" % (N, C1, C2, H)
+    x = T(pf.normal(tag + "x", (N, C1, H, H))).requires_grad_()
+    w1 = T(pf.normal(tag + "w1", (C2, C1, 3, 3)) / np.sqrt(C1 * 9)).requires_grad_()
+    b1 = T(pf.normal(tag + "b1", (C2,))).requires_grad_()
+    w2 = T(pf.normal(tag + "w2", (C2, C2, 3, 3)) / np.sqrt(C2 * 9)).requires_grad_()
+    b2 = T(pf.normal(tag + "b2", (C2,))).requires_grad_()
+    h = F.conv2d(F.leaky_relu(x, 0.2), w1, b1, padding=1)
+    y = F.avg_pool2d(F.conv2d(F.leaky_relu(h, 0.2), w2, b2, padding=1), 2)
+    r = T(pf.uniform(tag + "dy", tuple(y.shape)))
+    (y * r).sum().backward()
+    xg = nhwc(x).requires_grad_()
+    w1g, w2g = cl_weight(w1), cl_weight(w2)
+    b1g, b2g = (b.detach().float().to(dev()).requires_grad_() for b in (b1, b2))
+    hg, act = ops.conv2d_post_act(xg, w1g, b1g, pre_slope=0.2, post_slope=0.2)
+    assert act == expect_act, "which regime this shape was meant to exercise"
+    if act:   # the stored intermediate is lrelu(h)
+        assert relerr(nchw(hg), F.leaky_relu(h, 0.2)) < TOL
+    else:
+        assert relerr(nchw(hg), h) < TOL
+    yg = ops.conv2d(hg, w2g, b2g, pre_slope=0.2, pool=True, x_act=act)
+    assert relerr(nchw(yg), y) < TOL
+    (yg * nhwc(r)).sum().backward()
+    assert relerr(nchw(xg.grad), x.grad) < TOL, "dx"
+    for nm, got, ref in (("dw1", w1g.grad, w1.grad), ("db1", b1g.grad, b1.grad), ("dw2", w2g.grad, w2.grad), ("db2", b2g.grad, b2.grad)):
+        assert relerr(got.double().cpu(), ref) < TOL, nm
+
+
 def test_conv2d_residual_upsampled():
     """y = conv(x) + up2(res_low): residual stored at half resolution (skip of the up blocks)."""
     from optimalstrategiesagainstgenerativeattacks_amd import ops

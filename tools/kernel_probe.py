@@ -24,7 +24,8 @@ def main():
     fold = 1 if (pool or (ups and K > 1)) else 0
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, 0.2, pool, fold, 0, prec, tile, 0 if kind == "wgrad" else ks, ks if kind == "wgrad" else 0)
+    slope = float(os.environ.get("PROBE_SLOPE", "0.2"))   # pre-activation slope (1.0 = none)
+    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, slope, pool, fold, 0, prec, tile, 0 if kind == "wgrad" else ks, ks if kind == "wgrad" else 0)
     KF = K + 1 if fold else K
     x = torch.randn(N, H >> ups, H >> ups, Cin, device=dev)
     w = torch.randn(Cout, KF, KF, Cin, device=dev) * 0.05
