@@ -201,6 +201,12 @@ int gim_colsum2(const float* a, const float* b, float* out_a, float* out_b, int 
  * y = scale * (x - mean) / d + shift (+ residual).  stats [N][C][3] = {mean, 1/d, c2} saved for backward. */
 int gim_norm_fwd(const float* x, const float* scale, const float* shift, const float* residual, float* y, float* stats,
                  int N, int HW, int C, int mode, float eps, void* stream);
+/* The same with the output stored ACTIVATED, y = lrelu(scale * xhat + shift (+ residual), post_slope): the LeakyReLU the
+ * reference applies between a norm and the conv behind it (models/model_blocks.py:764,768,810,856,860), done here once per
+ * element so that that conv (gim_conv_shape.pre_slope = 1 for its forward and wgrad, the real slope for its dgrad mask) does
+ * not redo it per tap.  The backward (gim_norm_bwd) reads x and stats only and is unchanged. */
+int gim_norm_fwd_act(const float* x, const float* scale, const float* shift, const float* residual, float* y, float* stats,
+                     int N, int HW, int C, int mode, float eps, float post_slope, void* stream);
 /* dx, and per-(n,c) partials dscale_nc = sum dy*xhat, dshift_nc = sum dy  ([N][C] each). */
 int gim_norm_bwd(const float* dy, const float* x, const float* scale, const float* stats, float* dx, float* dscale_nc,
                  float* dshift_nc, int N, int HW, int C, int mode, void* stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "gim_spectral_sigma_batched": [P, c_int, P, c_int, P, c_int, P, c_int, P],
     "gim_colsum": [P, P, P, c_int64, c_int, P],
     "gim_norm_fwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "gim_norm_fwd_act": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P],
     "gim_norm_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_avgpool2_fwd": [P, P, c_int, c_int, c_int, c_int, P],
     "gim_avgpool2_bwd": [P, P, c_int, c_int, c_int, c_int, P],

@@ -51,7 +51,7 @@ template <int VEC, int CB>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        float* __restrict__ y, float* __restrict__ stats, int HW, int C, int mode,
-                                                       float eps) {
+                                                       float eps, float post_slope) {
     constexpr int CL = NormCfg<VEC, CB>::CL, HG = NormCfg<VEC, CB>::HG;
     __shared__ float red[HG * CB];
     const int n = blockIdx.y;
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] += rr[e];
         }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = fmaxf(o[e], o[e] * post_slope);   // 1 = identity (gim_norm_fwd_act)
         st_vec<VEC>(yb + (long long)i * C, o);
     }
 }
@@ -188,16 +190,27 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
     }
 }
 
-extern "C" int gim_norm_fwd(const float* x, const float* scale, const float* shift, const float* residual, float* y,
-                            float* stats, int N, int HW, int C, int mode, float eps, void* stream) {
+static int norm_fwd_impl(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                         float* stats, int N, int HW, int C, int mode, float eps, float post_slope, void* stream) {
     GIM_CHECK_ARG(x && scale && shift && y && stats, "norm_fwd: null pointer");
     GIM_CHECK_ARG(N > 0 && HW > 0 && C > 0 && (mode == 0 || mode == 1), "norm_fwd: bad dims");
     const bool vec = (C % 4 == 0) && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15);
     hipStream_t st = (hipStream_t)stream;
-    if (vec) hipLaunchKernelGGL((norm_fwd_kernel<4, 64>), dim3((C + 63) / 64, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps);
-    else if (C <= 4) hipLaunchKernelGGL((norm_fwd_kernel<1, 4>), dim3(1, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps);
-    else hipLaunchKernelGGL((norm_fwd_kernel<1, 64>), dim3((C + 63) / 64, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps);
+    if (vec) hipLaunchKernelGGL((norm_fwd_kernel<4, 64>), dim3((C + 63) / 64, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps, post_slope);
+    else if (C <= 4) hipLaunchKernelGGL((norm_fwd_kernel<1, 4>), dim3(1, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps, post_slope);
+    else hipLaunchKernelGGL((norm_fwd_kernel<1, 64>), dim3((C + 63) / 64, N), dim3(256), 0, st, x, scale, shift, residual, y, stats, HW, C, mode, eps, post_slope);
     return gim_check_launch("gim_norm_fwd");
+}
+
+extern "C" int gim_norm_fwd(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                            float* stats, int N, int HW, int C, int mode, float eps, void* stream) {
+    return norm_fwd_impl(x, scale, shift, residual, y, stats, N, HW, C, mode, eps, 1.0f, stream);
+}
+
+extern "C" int gim_norm_fwd_act(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                                float* stats, int N, int HW, int C, int mode, float eps, float post_slope, void* stream) {
+    GIM_CHECK_ARG(post_slope > 0.f && post_slope <= 1.f, "norm_fwd_act: post_slope must be in (0, 1]");
+    return norm_fwd_impl(x, scale, shift, residual, y, stats, N, HW, C, mode, eps, post_slope, stream);
 }
 
 extern "C" int gim_norm_bwd(const float* dy, const float* x, const float* scale, const float* stats, float* dx,

@@ -246,8 +246,8 @@ class GimInstanceNorm2d(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_features))
         self.bias = nn.Parameter(torch.zeros(num_features))
 
-    def forward(self, x):
-        return ops.instance_norm(x, self.weight, self.bias, self.eps)
+    def forward(self, x, post_slope=1.0):
+        return ops.instance_norm(x, self.weight, self.bias, self.eps, post_slope)
 
 
 def custom_std(x):
@@ -349,10 +349,11 @@ class ResBlockUp(nn.Module):
         # conv1x1(up(x)) = up(conv1x1(x)): the skip is computed at low resolution and upsampled by the residual
         # read of conv_r2; conv_r1(up(.)) runs in its sub-pixel form (ops.ConvFn)
         left = self.conv_l1(x)
-        out = self.in1(x)
-        out = self.conv_r1(out, ups=1, pre_slope=LRELU)
-        out = self.in2(out)
-        return self.conv_r2(out, res=left, res_ups=True, pre_slope=LRELU)
+        act = ops.act_storage()   # each norm output has ONE reader, a conv behind a LeakyReLU: the norm stores it activated
+        out = self.in1(x, post_slope=LRELU)
+        out = self.conv_r1(out, ups=1, pre_slope=LRELU, x_act=act)
+        out = self.in2(out, post_slope=LRELU)
+        return self.conv_r2(out, res=left, res_ups=True, pre_slope=LRELU, x_act=act)
 
 
 class AdaResBlock2(nn.Module):
@@ -376,8 +377,8 @@ class AdaResBlock2(nn.Module):
     def forward(self, x, style, sv=None):
         m1, s1, m2, s2 = sv if sv is not None else self.style_vectors(style)
         out = self.conv1(x)
-        out = ops.ada_in(out, m1, s1)
-        out = self.conv2(out, pre_slope=LRELU)
+        out = ops.ada_in(out, m1, s1, post_slope=LRELU)   # stored activated for conv2, its only reader
+        out = self.conv2(out, pre_slope=LRELU, x_act=ops.act_storage())
         return ops.ada_in(out, m2, s2, res=x)
 
 
@@ -402,7 +403,8 @@ class AdaResBlockUp2(nn.Module):
     def forward(self, x, style, sv=None):
         m1, s1, m2, s2 = sv if sv is not None else self.style_vectors(style)
         left = self.conv_l1(x)
-        out = ops.ada_in(x, m1, s1)
-        out = self.conv_r1(out, ups=1, pre_slope=LRELU)
-        out = ops.ada_in(out, m2, s2)
-        return self.conv_r2(out, res=left, res_ups=True, pre_slope=LRELU)
+        act = ops.act_storage()
+        out = ops.ada_in(x, m1, s1, post_slope=LRELU)
+        out = self.conv_r1(out, ups=1, pre_slope=LRELU, x_act=act)
+        out = ops.ada_in(out, m2, s2, post_slope=LRELU)
+        return self.conv_r2(out, res=left, res_ups=True, pre_slope=LRELU, x_act=act)

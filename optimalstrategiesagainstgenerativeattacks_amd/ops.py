@@ -716,7 +716,9 @@ class NormFn(Function):
     Optional residual added to the output.  x NHWC [N,H,W,C]."""
 
     @staticmethod
-    def forward(ctx, x, scale, shift, res, mode, eps):
+    def forward(ctx, x, scale, shift, res, mode, eps, post_slope=1.0):
+        """post_slope != 1: the output is stored ACTIVATED for a conv that is its only reader and runs with x_act (ConvFn): that
+        conv's dgrad hands back the gradient w.r.t. the RAW output, so this backward is unchanged (it never reads y)."""
         lib = _lib.load()
         x = _req(x, "x")
         scale_in, shift_in = scale, shift
@@ -727,7 +729,10 @@ class NormFn(Function):
         stats = torch.empty((N, C, 3), device=x.device, dtype=torch.float32)
         if res is not None:
             res = _req(res, "res")
-        check(lib.gim_norm_fwd(_p(x), _p(scale), _p(shift), _p(res), _p(y), _p(stats), N, H * W, C, mode, eps, _stream()), "norm_fwd")
+        if post_slope != 1.0:
+            check(lib.gim_norm_fwd_act(_p(x), _p(scale), _p(shift), _p(res), _p(y), _p(stats), N, H * W, C, mode, eps, post_slope, _stream()), "norm_fwd_act")
+        else:
+            check(lib.gim_norm_fwd(_p(x), _p(scale), _p(shift), _p(res), _p(y), _p(stats), N, H * W, C, mode, eps, _stream()), "norm_fwd")
         ctx.save_for_backward(x, scale, stats)
         ctx.cfg = (N, H * W, C, mode, res is not None)
         ctx.scale_param, ctx.shift_param = (scale_in, shift_in) if mode == 0 else (None, None)
@@ -761,15 +766,21 @@ class NormFn(Function):
                 check(lib.gim_colsum2(_p(dsc), _p(dsh), _p(dscale), _p(dshift), N, C, 0, st), "colsum2")
         else:
             dscale, dshift = dsc.view_as(scale), dsh.view_as(scale)
-        return dx, dscale, dshift, (dy if has_res else None), None, None
+        return dx, dscale, dshift, (dy if has_res else None), None, None, None
 
 
-def instance_norm(x, weight, bias, eps=1e-5):
-    return NormFn.apply(x, weight, bias, None, 0, eps)
+def instance_norm(x, weight, bias, eps=1e-5, post_slope=1.0):
+    """post_slope != 1 (and activated storage on): returns lrelu(y) for a conv called with x_act=True - see NormFn.forward."""
+    return NormFn.apply(x, weight, bias, None, 0, eps, post_slope if _ACT_STORAGE else 1.0)
 
 
-def ada_in(x, mean_style, std_style, res=None, eps=1e-5):
-    return NormFn.apply(x, std_style, mean_style, res, 1, eps)
+def ada_in(x, mean_style, std_style, res=None, eps=1e-5, post_slope=1.0):
+    return NormFn.apply(x, std_style, mean_style, res, 1, eps, post_slope if _ACT_STORAGE else 1.0)
+
+
+def act_storage():
+    """Is activated storage in use (ops.conv2d_post_act / norm post_slope + x_act consumers)?  Host-side A/B switch GIM_NO_ACT_STORAGE."""
+    return _ACT_STORAGE
 
 
 # --------------------------------------------------------------------------------------------
