@@ -991,7 +991,8 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
 #pragma unroll
                 for (int e = 0; e < VA; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.a_slope, p.pos_inf);
         }
-        if (do_bias) {
+        if (do_bias) {   // block-uniform (first column tile only)
+            asm volatile("" ::: "memory");   // keeps this a real branch: if-converted, its adds + selects ran in EVERY workgroup's K loop
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
 #pragma unroll
