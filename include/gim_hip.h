@@ -223,6 +223,12 @@ int gim_upsample2x_bwd(const float* dy_up, const float* mask_x, float slope, flo
 int gim_maxpool_lrelu_fwd(const float* x, float* y, int32_t* idx, int N, int HW, int C, float slope, void* stream);
 int gim_maxpool_lrelu_bwd(const float* dy, const float* y, const int32_t* idx, float* dx, int N, int HW, int C, float slope, void* stream);
 
+/* Attention probabilities in ONE kernel: P[b][i][j] = softmax over i of f[b][i][:] . g[b][j][:]  - the energy bmm and the
+ * Softmax(dim=-2) of SelfAttention.forward (models/model_blocks.py:540-543) without the round trip of the T x T energy through
+ * memory.  f, g [batch][T][K] (token-major, K contiguous), P [batch][T][T].  Built for T = 256, K = 16 (GIM_E_BADARG otherwise:
+ * callers fall back to gim_bgemm + gim_softmax_dim1_fwd).  The backward is the unfused one (gim_softmax_dim1_bwd + gim_bgemm). */
+int gim_attn_prob_fwd(const float* f, const float* g, float* P, int batch, int T, int K, void* stream);
+
 /* Batched strided GEMM  C[b](i,j) = sum_k A[b](i,k) * B[b](k,j)  (torch.bmm in SelfAttention,
  * models/model_blocks.py:539-544 and their autograd).  Element strides; C is row-major [b][M][N]. */
 int gim_bgemm(const float* A, const float* B, float* C, int batch, int M, int N, int K,

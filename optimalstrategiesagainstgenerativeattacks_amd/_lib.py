@@ -43,6 +43,7 @@ SIGNATURES = {
     "gim_maxpool_lrelu_fwd": [P, P, P, c_int, c_int, c_int, c_float, P],
     "gim_maxpool_lrelu_bwd": [P, P, P, P, c_int, c_int, c_int, c_float, P],
     "gim_bgemm": [P, P, P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, P],
+    "gim_attn_prob_fwd": [P, P, P, c_int, c_int, c_int, P],
     "gim_softmax_dim1_fwd": [P, P, c_int, c_int, c_int, P],
     "gim_softmax_dim1_bwd": [P, P, P, c_int, c_int, c_int, P],
     "gim_scale_add_fwd": [P, P, P, P, c_int64, P],

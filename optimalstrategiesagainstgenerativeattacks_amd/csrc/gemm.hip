@@ -176,6 +176,118 @@ __global__ __launch_bounds__(256) void bgemm_vec_kernel(const BgP p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Attention probabilities in one kernel:  P[b][i][j] = softmax_i( f[b][i][:] . g[b][j][:] )   (models/model_blocks.py:540-543:
+// energy = bmm(f^T, g), Softmax(dim=-2)).  The unfused form writes the energy (T x T per image), reads it back for the softmax
+// and writes P - 3 passes over 21 MB at the benchmark shape for a product with K = C/8 = 16.  Here one workgroup owns ALL T
+// rows of a block of 64 columns: the energy tile lives in the MFMA accumulators, the column maxima and sums are reduced through
+// the wave (lanes r / r + 32 hold different rows of a column) and 2 KB of LDS (the four waves), and only P is written.
+// T = 256 tokens (the 16 x 16 map the attention sits on at 64 x 64 and 128 x 128 input), K = 16.
+// -------------------------------------------------------------------------------------------------
+#define AT_T 256
+#define AT_K 16
+#define AT_LD 260   // k-major LDS rows of the f tile (256 + pad, 16-byte aligned)
+__global__ __launch_bounds__(256) void attn_prob_kernel(const float* __restrict__ f, const float* __restrict__ g, float* __restrict__ P) {
+    __shared__ __attribute__((aligned(16))) float Fs[AT_K * AT_LD];   // [k][i]
+    __shared__ __attribute__((aligned(16))) float Gs[AT_K * 68];      // [k][j]
+    __shared__ float red[4][64];
+    const int t = threadIdx.x, b = blockIdx.y, j0 = blockIdx.x * 64;
+    const float* fb = f + (long long)b * AT_T * AT_K;
+    const float* gb = g + ((long long)b * AT_T + j0) * AT_K;
+    // f: 256 rows x 16 k = 1024 float4, 4 per thread; g: 64 rows x 16 k = 256 float4, 1 per thread; stored k-major
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = t + 256 * e, i = idx >> 2, kq = idx & 3;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (long long)i * AT_K + 4 * kq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Fs[(4 * kq + q) * AT_LD + i] = v[q];
+    }
+    {
+        const int j = t >> 2, kq = t & 3;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(gb + (long long)j * AT_K + 4 * kq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Gs[(4 * kq + q) * 68 + j] = v[q];
+    }
+    __syncthreads();
+    const int lane = t & 63, r = lane & 31, h = lane >> 5, wv = t >> 6;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rb][cb][e] = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < AT_K / 2; ++kp) {
+        float a[2], bb[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) a[rb] = Fs[(2 * kp + h) * AT_LD + 64 * wv + 32 * rb + r];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) bb[cb] = Gs[(2 * kp + h) * 68 + 32 * cb + r];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb], bb[cb], acc[rb][cb], 0, 0, 0);
+    }
+    // column (j) statistics over all 256 rows: in-lane over 32 rows, across the two lane halves, across the four waves
+    float mx[2], sm[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[rb][cb][e]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (h == 0) red[wv][32 * cb + r] = m;
+        mx[cb] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int c = 32 * cb + r;
+        mx[cb] = fmaxf(fmaxf(red[0][c], red[1][c]), fmaxf(red[2][c], red[3][c]));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        float s = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[rb][cb][e] = __expf(acc[rb][cb][e] - mx[cb]);
+                s += acc[rb][cb][e];
+            }
+        s += __shfl_xor(s, 32);
+        if (h == 0) red[wv][32 * cb + r] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int c = 32 * cb + r;
+        sm[cb] = 1.0f / (red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    }
+    float* Pb = P + (long long)b * AT_T * AT_T + j0;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = 64 * wv + 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                Pb[(long long)i * AT_T + 32 * cb + r] = acc[rb][cb][e] * sm[cb];
+            }
+}
+
+extern "C" int gim_attn_prob_fwd(const float* f, const float* g, float* P, int batch, int T, int K, void* stream) {
+    GIM_CHECK_ARG(f && g && P && batch > 0, "attn_prob_fwd: bad args");
+    GIM_CHECK_ARG(T == AT_T && K == AT_K, "attn_prob_fwd: built for T = 256 tokens and K = 16 channels (use gim_bgemm + gim_softmax_dim1_fwd otherwise)");
+    GIM_CHECK_ARG(batch <= 65535 && !(((uintptr_t)f | (uintptr_t)g) & 15), "attn_prob_fwd: batch too large for grid.y or operands not 16-byte aligned");
+    hipLaunchKernelGGL(attn_prob_kernel, dim3(AT_T / 64, batch), dim3(256), 0, (hipStream_t)stream, f, g, P);
+    return gim_check_launch("gim_attn_prob_fwd");
+}
+
 extern "C" int gim_bgemm(const float* A, const float* B, float* C, int batch, int M, int N, int K, int64_t sAb, int64_t sAi,
                          int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, void* stream) {
     GIM_CHECK_ARG(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0, "bgemm: bad args");

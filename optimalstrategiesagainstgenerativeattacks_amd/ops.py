@@ -1068,11 +1068,47 @@ class SoftmaxDim1BwdFn(Function):
         return g_dP, g_P
 
 
+class AttnProbFn(Function):
+    """A[b] = softmax over dim 1 of f[b] g[b]^T in ONE kernel (gim_attn_prob_fwd: the T x T energy never goes through memory) for
+    the shape the benchmark networks use (T = 256 tokens, C/8 = 16 channels).  Its backward is the unfused one, expressed through
+    SoftmaxDim1BwdFn and BgemmFn so that it stays differentiable (the R1 term differentiates the discriminator's attention twice)."""
+
+    @staticmethod
+    def supported(f, g):
+        return f.dim() == 3 and f.shape[1] == 256 and f.shape[2] == 16 and g.shape == f.shape
+
+    @staticmethod
+    def forward(ctx, f, g):
+        f, g = _req(f, "f"), _req(g, "g")
+        nb, T, K = f.shape
+        A = torch.empty((nb, T, T), device=f.device, dtype=torch.float32)
+        if _FLOPS is not None:
+            ent = _FLOPS.setdefault(("bgemm", (nb, T, T, K)), [0, 2.0 * nb * T * T * K])
+            ent[0] += 1
+        check(_lib.load().gim_attn_prob_fwd(_p(f), _p(g), _p(A), nb, T, K, _stream()), "attn_prob_fwd")
+        ctx.save_for_backward(f, g, A)
+        return A
+
+    @staticmethod
+    def backward(ctx, dA):
+        f, g, A = ctx.saved_tensors
+        dS = SoftmaxDim1BwdFn.apply(dA, A)
+        df = BgemmFn.apply(dS, g, 0, 0) if ctx.needs_input_grad[0] else None     # S = f g^T: dS g
+        dg = BgemmFn.apply(dS, f, 1, 0) if ctx.needs_input_grad[1] else None     #            dS^T f
+        return df, dg
+
+
 def attn_core(f, g, h):
     """out[b, j, :] = sum_i softmax_i(f[b,i,:] . g[b,j,:]) * h[b,i,:]   (tokens = pixels, NHWC rows)."""
-    S = BgemmFn.apply(f, g, 0, 1)        # S[i, j] = f_i . g_j
-    A = SoftmaxDim1Fn.apply(S)
+    if _FUSED_ATTN and AttnProbFn.supported(f, g):
+        A = AttnProbFn.apply(f, g)
+    else:
+        S = BgemmFn.apply(f, g, 0, 1)        # S[i, j] = f_i . g_j
+        A = SoftmaxDim1Fn.apply(S)
     return BgemmFn.apply(A, h, 1, 0)     # out = A^T h
+
+
+_FUSED_ATTN = os.environ.get("GIM_NO_FUSED_ATTN") is None   # A/B switch (host side)
 
 
 # --------------------------------------------------------------------------------------------
