@@ -341,10 +341,14 @@ def main():
     def timed(label):
         """W warm-up steps, then EXACTLY K steps between barrier + synchronize;
         (seconds [max over ranks], device ms of the region, per-step device ms on the caller's stream, last out)."""
+        # the warm-up steps run the way the timed ones do - enqueued back to back, next iteration under the tail of the previous
+        # one - so that the allocator pools, the lane streams and (multi-GPU) the communicator have seen that pattern before the
+        # timed region starts; one synchronisation at their end
         for i in range(args.warmup):
             out = step()
-            torch.cuda.synchronize()
-            log("%s: warm-up step %d done" % (label, i))
+        _ops.join_lanes()
+        torch.cuda.synchronize()
+        log("%s: %d warm-up steps done" % (label, args.warmup))
         gc.collect()   # start the timed region with an empty young generation (a full collection mid-region stalls the enqueue thread)
         fence()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
