@@ -49,7 +49,8 @@ def _use_side_streams(t):
 _STREAM_MAP = [int(v) for v in os.environ.get("GIM_STREAM_MAP", "0,1,2,2,0").split(",")]
 assert len(_STREAM_MAP) == 5, "GIM_STREAM_MAP: five comma-separated stream ids (roles 0..4)"
 # The bf16x3 matrix path runs at the board's power limit and gains nothing from a second stream inside lane 1: with lane 1 on ONE
-# stream it is 6 % faster (439.8 vs 414.5 episodes/s, profiles/r02_stream_map_sweep_final_build.txt); the fp32 path keeps the map above.
+# stream it is 1-2 % faster in alternating runs (468 / 461 / 454 against 458 / 455 / 451 episodes/s on one box; 439.8 vs 414.5 in
+# profiles/r02_stream_map_sweep_final_build.txt); the fp32 path keeps the map above.
 _STREAM_MAP_X3 = _STREAM_MAP if "GIM_STREAM_MAP" in os.environ else [0, 1, 2, 2, 2]
 _POOL = {}
 
