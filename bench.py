@@ -421,12 +421,15 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world,
                        "backend": dist.get_backend() if dist.is_initialized() else None,
                        "launch": "hipGraph replay" if args.graph else "eager", "matrix_path": matrix_path},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "what": "achieved / frac: ALGORITHMIC FLOPs (SURVEY.md 8(d): the unfused reference ops at full resolution) per second; the "
-                                 "matrix-pipe utilisation is executed_frac: FLOPs the kernels execute (pool / sub-pixel folds: (K+1)^2 taps at a "
-                                 "quarter of the pixels), counted per launch over one step",
+            "roofline": {"bound": "mfma", "achieved": round(executed, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "what": "achieved / frac: FLOPs the kernels EXECUTE per second (every conv / linear / batched-GEMM launch of one step "
+                                 "counted per launch; the pool / sub-pixel folds run (K+1)^2 taps at a quarter of the pixels) over the fp32 MFMA "
+                                 "peak = the matrix-pipe utilisation of the step (<= 1 by construction).  algo_tflops / algo_frac: the "
+                                 "ALGORITHMIC figure of SURVEY.md 8(d) (the unfused reference ops at full resolution) - it counts taps the "
+                                 "folded kernels never execute and can exceed 1; it is not a utilisation",
                          "algo_gflop_per_episode": round(algo, 1), "algo_gflop_per_step": round(algo * B, 1),
+                         "algo_tflops": round(achieved, 3), "algo_frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "executed_gflop_per_step": round(exe_gf, 1), "executed_tflops": round(executed, 3),
                          "executed_frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
                          "launched_ops_at_full_resolution_gflop_per_step": round(algo_launch_gf, 1),

@@ -9,6 +9,7 @@ There is no CPU compute path: forward/backward/step need an MI355X and the built
 from .gim_img_models import (AdaInImage2Image, Encoder, EnvDecoder, GIMFaceAuthenticator, GIMFaceDis,
                              GIMFaceImpersonator, get_au, get_im)
 from .gim_gaussian_trainer import GIMGaussianTrainer
+from .gim_gaussian_training import train_gim_gaussian
 from .gim_img_trainer import GIMImgTrainer
 from .data import EpisodeBank, synthetic_bank
 from .gim_img_training import (au_eval_step, au_train_step, eval_step, gim_step, im_eval_step, im_train_step, train_epoch,
@@ -20,5 +21,5 @@ from .training_utils import CheckpointIO, DataParallelMock, EpisodeParallel, Glo
 __all__ = [
     "get_au", "get_im", "Encoder", "EnvDecoder", "AdaInImage2Image", "GIMFaceDis", "GIMFaceAuthenticator",
     "GIMFaceImpersonator", "GIMImgTrainer", "GIMGaussianTrainer", "im_train_step", "au_train_step", "im_eval_step", "au_eval_step",
-    "gim_step", "train_epoch", "eval_step", "train_gim_imgs", "EpisodeBank", "synthetic_bank", "Logger", "FusedAdam", "DataParallelMock", "EpisodeParallel", "GlobalStep", "CheckpointIO", "adjust_batch_size",
+    "gim_step", "train_epoch", "eval_step", "train_gim_imgs", "train_gim_gaussian", "EpisodeBank", "synthetic_bank", "Logger", "FusedAdam", "DataParallelMock", "EpisodeParallel", "GlobalStep", "CheckpointIO", "adjust_batch_size",
 ]

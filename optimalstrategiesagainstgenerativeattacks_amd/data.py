@@ -61,7 +61,11 @@ class EpisodeSampler:
     def epoch_rows(self, batch_size, shuffle, drop_last=True, rank=0, world=1):
         """Per global batch of one epoch: the class rows of THIS rank's slice (what DataLoader(shuffle, drop_last) + the
         episode-dim scatter of nn.DataParallel give, training/gim_img_training.py:210,409)."""
-        assert batch_size % world == 0, "the global batch must divide by the number of ranks (training/utils.py:167-171)"
+        if batch_size % world != 0:
+            raise ValueError("the global batch (%d) must divide by the number of ranks (%d) (training/utils.py:167-171)" % (batch_size, world))
+        if world > 1 and not drop_last:
+            raise ValueError("drop_last=False with more than one rank: the short last batch would leave ranks with unequal or empty "
+                             "slices (mismatched collectives); the training loop always drops it (training/gim_img_training.py:210)")
         order = np.arange(len(self))
         if shuffle:
             self.shuffle_rng.shuffle(order)     # identical on every rank: same seed, and nothing else draws from this generator

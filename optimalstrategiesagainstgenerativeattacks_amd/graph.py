@@ -51,6 +51,13 @@ class GraphedGimStep:
             if isinstance(m_, mb.SNConv2d):
                 m_._fold_cache = (None, None, None, None, False)
         ops._WT_CACHE.clear()
+        # The weight-gradient arenas were re-zeroed by the flush INSIDE the capture: their "zeroed" marks hold an event that was
+        # recorded on a capturing stream only.  An eager backward on another stream would wait on that event from outside the
+        # capture (undefined in HIP).  Re-mark every page eagerly (the arena is zero: nothing ran since the warm-up's own flush).
+        torch.cuda.synchronize()
+        for q in ops._QUEUES.values():
+            for pg in q.pages:
+                pg[2:] = q._zeroed_mark()
 
     def __call__(self, leaked, real, si, z):
         for dst, src in zip(self.static, (leaked, real, si, z)):

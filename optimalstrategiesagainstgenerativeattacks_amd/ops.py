@@ -167,14 +167,15 @@ def _splits_k(sh, plan_kind, key):
 
 def _zeros_from_pool(shape, device):
     """A zero-filled float32 tensor of `shape`, cleared together with its neighbours by one fill per 64 MB page (pages are per
-    stream: the fill and the kernels that use the page are in stream order)."""
+    (device, stream): the fill and the kernels that use the page are in stream order).  A view keeps its WHOLE page alive: outputs
+    that live for one training step (saved activations) cost nothing extra, a tensor a caller keeps for long pins 64 MB - clone it."""
     n = 1
     for d in shape:
         n *= d
     na = (n + 63) & ~63
     if na > _ZERO_PAGE >> 1:     # a big output: its own fill (a view pins its whole page for as long as it lives)
         return torch.zeros(shape, device=device, dtype=torch.float32)
-    raw = _stream()
+    raw = (torch._C._cuda_getDevice(), _stream())
     pg = _ZERO_PAGES.get(raw)
     if pg is None or pg[1] + na > pg[0].numel():
         pg = _ZERO_PAGES[raw] = [torch.zeros(_ZERO_PAGE, device=device, dtype=torch.float32), 0]
@@ -439,10 +440,11 @@ class ConvFn(Function):
         sh = _shape(N, H, W, Cin, Cout, KH, ups, 1.0 if x_act else pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
         Ho, Wo = (H >> 1, W >> 1) if pool else (H, W)
         key = (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold)
-        # post_slope: store lrelu(y) for a consumer that is the ONLY reader of y and runs with x_act (conv2d_post_act decides);
-        # impossible when the launch splits K (the slices combine by addition)
-        _POST_APPLIED[0] = _ACT_STORAGE and post_slope != 1.0 and x.dim() == 4 and not _splits_k(sh, 0, key)
-        if _POST_APPLIED[0]:
+        # post_slope != 1: store lrelu(y) for a consumer that is the ONLY reader of y and runs with x_act.  conv2d_post_act has
+        # resolved it (1.0 when the launch splits K: the slices combine by addition); a split-K launch refuses it here
+        if post_slope != 1.0:
+            if x.dim() != 4 or _splits_k(sh, 0, key):
+                raise RuntimeError("conv: an activated output (post_slope) cannot be combined with a split-K launch or a linear layer")
             sh.post_slope = post_slope
         y = _conv_out(sh, 0, key, (N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), x.device)
         if res is not None:
@@ -501,7 +503,6 @@ class ConvFn(Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
-_POST_APPLIED = [False]   # did the last ConvFn.forward store its output activated?  (read by conv2d_post_act right after the call)
 _ACT_STORAGE = os.environ.get("GIM_NO_ACT_STORAGE") is None   # A/B switch (host side)
 _NARROW_DGRAD_T = os.environ.get("GIM_NO_NARROW_DGRAD_T") is None   # A/B switch (host side)
 _WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
@@ -697,8 +698,18 @@ def conv2d_post_act(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, u
     of y and is then called with x_act=True (it skips its per-tap LeakyReLU in forward and wgrad; its dgrad masks by the sign,
     which activation does not change, and hands back the gradient w.r.t. the RAW y - so this conv's backward is unchanged).
     Returns (y_stored, activated): launches that split K cannot activate (their slices combine by addition) and return raw y."""
-    y = ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope, False)
-    return y, _POST_APPLIED[0]
+    act = False
+    if _ACT_STORAGE and post_slope != 1.0 and x.dim() == 4:
+        # decided HERE, for this call's own shape, and handed to ConvFn as the resolved slope: nothing about the stored form of y
+        # travels through module state (another conv running in between could not change what this call reports)
+        N, Hs, Ws, Cin = x.shape
+        Cout, KH = w.shape[0], (w.shape[2] if w.dim() == 4 else 1)
+        H, W = Hs << ups, Ws << ups
+        fold = 1 if (pool or (ups and KH > 1)) else 0
+        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
+        act = not _splits_k(sh, 0, (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold))
+    y = ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope if act else 1.0, False)
+    return y, act
 
 
 def linear(x, w, bias=None, pre_slope=1.0):

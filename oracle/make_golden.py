@@ -247,14 +247,25 @@ def tensor_stats(sd):
     return {k: [float(v.double().sum()), float(v.double().norm())] for k, v in sd.items()}
 
 
-def gen_trainer(tag, reg_param, n_steps=3, n_au_steps=1):
+def state_samples(prefix, sd, st, cap=512):
+    """Strided sample (prime stride, at most `cap` values, float64) of every tensor of a state dict: pins element positions,
+    which the per-tensor (sum, norm) pair cannot."""
+    for kk, v in sd.items():
+        a = v.detach().double().reshape(-1).numpy()
+        stride = next(p_ for p_ in (1, 3, 7, 13, 31, 61, 127, 251, 509, 1021, 2039, 4093, 8191, 16381) if p_ * cap >= a.size)
+        st["%s/%d/%s" % (prefix, stride, kk)] = a[::stride].copy()
+
+
+def gen_trainer(tag, reg_param, n_steps=3, n_au_steps=1, lrs=(2e-3, 1e-3, 1e-4)):
     """Trainer protocol (real im_train_step / au_train_step of the reference) on the tiny
-    config for n_steps consecutive iterations, fp64."""
+    config for n_steps consecutive iterations, fp64.  lrs = (au_lr, im_lr, noise-mapper lr): the R1 fixture runs at the
+    REAL learning rates of the path (1e-4 / 1e-4 / 1e-6, train_gim_on_imgs.py defaults): at 2e-3 the reference's own fp32 run leaves
+    its fp64 run by 1e-2 on the third iteration (profiles/r02_trainer_fixture_fp32_noise.txt) and the fixture pins nothing there."""
     s, c, d, B, m, n, k = 16, 1, 32, 3, 1, 3, 4
     torch.set_default_dtype(torch.float64)
     au, im = make_models(s, c, d, tag + "/", torch.float64)
     with tempfile.TemporaryDirectory() as td:
-        tr = GIMImgTrainer(td, m, n, k, au, im, au_lr=2e-3, im_lr=1e-3, env_noise_mapping_lr=1e-4,
+        tr = GIMImgTrainer(td, m, n, k, au, im, au_lr=lrs[0], im_lr=lrs[1], env_noise_mapping_lr=lrs[2],
                            lr_milestones=(2,), lr_gamma=0.5, reg_param=reg_param)
     trainer = DataParallelMock(tr)
     st, meta = {}, {"lrs": []}
@@ -290,10 +301,16 @@ def gen_trainer(tag, reg_param, n_steps=3, n_au_steps=1):
     meta["im_opt_n_groups"] = len(tr.impersonator_opt.param_groups)
     first = next(iter(tr.authenticator_opt.state.values()))
     meta["au_opt_first_v_norm"] = float(first["exp_avg_sq"].norm())
+    # element samples of the state the protocol leaves behind: every parameter / buffer of both agents, and Adam's second
+    # moment of every parameter that has one (keyed by parameter NAME)
+    state_samples("final/au", au.state_dict(), st)
+    state_samples("final/im", im.state_dict(), st)
+    for nm, mod, opt in (("au", au, tr.authenticator_opt), ("im", im, tr.impersonator_opt)):
+        state_samples("adam_v/" + nm, {kk: opt.state[p_]["exp_avg_sq"] for kk, p_ in mod.named_parameters() if p_ in opt.state}, st)
     np.savez_compressed(os.path.join(OUT, "trainer_%s.npz" % tag), **st)
     with open(os.path.join(OUT, "trainer_%s.json" % tag), "w") as f:
         json.dump({"config": dict(s=s, c=c, d=d, B=B, m=m, n=n, k=k, reg_param=reg_param, n_au_steps=n_au_steps,
-                                  au_lr=2e-3, im_lr=1e-3, noise_lr=1e-4, milestones=[2], gamma=0.5), "meta": meta}, f)
+                                  au_lr=lrs[0], im_lr=lrs[1], noise_lr=lrs[2], milestones=[2], gamma=0.5), "meta": meta}, f)
     torch.set_default_dtype(torch.float32)
     print("trainer_%s: done" % tag)
 
@@ -337,6 +354,48 @@ def gen_gaussian():
         json.dump({"config": dict(d=d, B=B, m=m, n=n, k=k, au_lr=1e-3, im_lr=2e-3, sigma=0.7), "keys": keys}, f)
     torch.set_default_dtype(torch.float32)
     print("gaussian: done")
+
+
+def gen_gaussian_loop():
+    """BASELINE config 1's CALLER: the reference's own train() (training/gim_gaussian_training.py:50-151) for 5 iterations on the
+    CPU with a seeded default generator - it draws mu and the three sample sets per iteration with torch.normal and the latent
+    z with torch.randn inside the impersonator (models/gim_gaussian_models.py:81), all from that one generator - recording every
+    logger call (float32, the dtype the reference runs in); plus known answers of theory/theoretic_game_value.py:10-20 (game_value_mnk), the quantity the toy game converges to."""
+    import models.gim_gaussian_models as ggm
+    from training.gim_gaussian_trainer import GIMGaussianTrainer
+    import training.gim_gaussian_training as ggt
+    from theory.theoretic_game_value import game_value_mnk
+    d, B, m, n, k = 10, 64, 1, 5, 10
+    cfg = dict(d=d, B=B, m=m, n=n, k=k, au_lr=1e-3, im_lr=2e-3, src_sigma=1.0, prior_sigma=2.0, n_iters=5, seed=77,
+               save_stats_every=2, save_every=4, reg_param=0.0)
+    tag = "gauss_loop"
+    # float32, the reference's native dtype: torch.normal draws a different stream in float64, and the draws are part of the pin
+    torch.set_default_dtype(torch.float32)
+    au = fill_module(ggm.get_au(d), tag + "/au/", torch.float32)
+    im = fill_module(ggm.get_im(d), tag + "/im/", torch.float32)
+    rec = _Recorder()
+    saves = []
+    st = {}
+    with tempfile.TemporaryDirectory() as td:
+        tr = GIMGaussianTrainer(td, m, n, k, au, im, au_lr=cfg["au_lr"], im_lr=cfg["im_lr"], reg_param=cfg["reg_param"])
+        tr.save = lambda: saves.append(int(tr.global_step))
+        trainer = DataParallelMock(tr)
+        torch.manual_seed(cfg["seed"])
+        ggt.tqdm = lambda it, **kw: it
+        ggt.train(device="cpu", trainer=trainer, logger=rec, n_iters=cfg["n_iters"], batch_size=B, src_dim=d, src_sigma=cfg["src_sigma"],
+                  prior_sigma=cfg["prior_sigma"], save_stats_every=cfg["save_stats_every"], save_every=cfg["save_every"])
+    for kk, v in au.state_dict().items():
+        st["final/au/" + kk] = v.numpy()
+    for kk, v in im.state_dict().items():
+        st["final/im/" + kk] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "gaussian_loop.npz"), **st)
+    kats = [[m_, n_, d_, k_, float(game_value_mnk(m_, n_, d_, k_))] for (m_, n_, d_, k_) in
+            ((1, 5, 10, 10), (1, 5, 100, 10), (1, 1, 10, 10), (5, 2, 10, 3), (2, 10, 4, 1), (1, 100, 1, 1000), (3, 4, 64, 7))]
+    with open(os.path.join(OUT, "gaussian_loop.json"), "w") as f:
+        json.dump({"config": cfg, "scalars": rec.scalars, "saves": saves, "final_global_step": int(tr.global_step),
+                   "game_value_mnk": kats}, f)
+    torch.set_default_dtype(torch.float32)
+    print("gaussian_loop: %d scalars, saves %s" % (len(rec.scalars), saves))
 
 
 def gen_subnets():
@@ -385,11 +444,13 @@ def gen_bench_grads(tag, s, c, d, B, m, n, k, dtype):
     last = len(au.src_encoder.down_blocks) - 1
     gi = grads_of(im)
 
-    def sample(prefix, name, arr):   # at most ~20 000 values per tensor, prime stride, float32 (compared at 1e-3)
-        stride = next(p_ for p_ in (1, 3, 7, 13, 31, 61, 127, 251, 509, 1021, 2039) if p_ * 20000 >= arr.size)
+    def sample(prefix, name, arr, cap=20000):   # at most ~20 000 values per tensor, prime stride, float32 (compared at 1e-3)
+        stride = next(p_ for p_ in (1, 3, 7, 13, 31, 61, 127, 251, 509, 1021, 2039, 4093, 8191) if p_ * cap >= arr.size)
         st["%s/%d/%s" % (prefix, stride, name)] = arr.reshape(-1)[::stride].astype(np.float32)
     for name in BENCH_GRAD_SAMPLES["im"]:
         sample("g", name, gi[name])
+    for name, arr in gi.items():     # EVERY parameter gradient of the G step, thinner (<= 1500 values each)
+        sample("g_all", name, arr, cap=1500)
     au.zero_grad(); im.zero_grad()
     res = tr.forward(mode="authenticator_forward", fake_sample=fake.detach(), real_sample=real, si_sample=si)
     res[0].mean().backward()
@@ -397,6 +458,8 @@ def gen_bench_grads(tag, s, c, d, B, m, n, k, dtype):
     for name in BENCH_GRAD_SAMPLES["au"]:
         name = name % {"last": last}
         sample("d", name, ga[name])
+    for name, arr in ga.items():     # EVERY parameter gradient of the D step
+        sample("d_all", name, arr, cap=1500)
     np.savez_compressed(os.path.join(OUT, "nets_%s_grads.npz" % tag), **st)
     torch.set_default_dtype(torch.float32)
     print("nets_%s_grads: %d arrays, %d values" % (tag, len(st), sum(v.size for v in st.values())))
@@ -414,7 +477,7 @@ def gen_ckpt():
     au, im = make_models(s, c, d, tag + "/", torch.float32)
     st = {}
     with tempfile.TemporaryDirectory() as td:
-        tr = GIMImgTrainer(td, m, n, k, au, im, au_lr=2e-3, im_lr=1e-3, env_noise_mapping_lr=1e-4, reg_param=0.0)
+        tr = GIMImgTrainer(td, m, n, k, au, im, au_lr=1e-4, im_lr=1e-4, env_noise_mapping_lr=1e-6, reg_param=0.0)
         trainer = DataParallelMock(tr)
         for it in range(4):
             leaked, real, si, z = episode("%s/it%d" % (tag, it), B, m, n, k, c, s, d, torch.float32)
@@ -434,7 +497,7 @@ def gen_ckpt():
                     st["d_" + nm] = np.asarray(dres[i].numpy())
     np.savez_compressed(os.path.join(OUT, "ref_ckpt_step4.npz"), **st)
     with open(os.path.join(OUT, "ref_ckpt.json"), "w") as f:
-        json.dump({"config": dict(s=s, c=c, d=d, B=B, m=m, n=n, k=k, au_lr=2e-3, im_lr=1e-3, noise_lr=1e-4, tag=tag),
+        json.dump({"config": dict(s=s, c=c, d=d, B=B, m=m, n=n, k=k, au_lr=1e-4, im_lr=1e-4, noise_lr=1e-6, tag=tag),
                    "au_keys": key_list(au), "im_keys": key_list(im),
                    "size_bytes": os.path.getsize(os.path.join(OUT, "ref_ckpt_model_00000002.pt"))}, f)
     print("ref_ckpt: done")
@@ -615,9 +678,11 @@ def gen_data():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "keys", "tiny", "trainer", "bench", "gaussian", "subnets", "benchgrads", "ckpt", "loop", "data"]
+    which = sys.argv[1:] or ["blocks", "keys", "tiny", "trainer", "bench", "gaussian", "gaussloop", "subnets", "benchgrads", "ckpt", "loop", "data"]
     if "gaussian" in which:
         gen_gaussian()
+    if "gaussloop" in which:
+        gen_gaussian_loop()
     if "blocks" in which:
         gen_blocks()
     if "keys" in which:
@@ -628,7 +693,7 @@ def main():
         gen_nets("tiny_att", 16, 1, 32, 2, 1, 3, 4, torch.float64, full=False, use_img_att=True)
     if "trainer" in which:
         gen_trainer("reg0", 0.0)
-        gen_trainer("reg10", 10.0)
+        gen_trainer("reg10", 10.0, lrs=(1e-4, 1e-4, 1e-6))
         gen_trainer("nau2", 0.0, n_steps=2, n_au_steps=2)
     if "bench" in which:
         gen_nets("om32_f64", 32, 1, 512, 2, 1, 5, 10, torch.float64, full=False)

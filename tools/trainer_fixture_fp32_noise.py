@@ -4,6 +4,7 @@ protocol fixtures (tests/golden/trainer_*.npz), per iteration: the noise floor a
 import os
 import sys
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -49,6 +50,30 @@ for tag in ("reg0", "reg10", "nau2"):
             dev_ = max(abs(float(t.norm()) - n_ref) / max(n_ref, 1e-30), abs(float(t.sum()) - s_ref) / max(n_ref * t.numel() ** 0.5, 1e-30))
             worst = max(worst, (dev_, k))
         fin.append("%s final state: worst tensor %.1e (%s)" % (nm, worst[0], worst[1]))
+    # element samples of the final state / of Adam's second moments (fixture keys final/<agent>/<stride>/<name>, adam_v/...)
+    for nm, sd, opt in (("au", au, tr.au_opt), ("im", im, tr.im_opt)):
+        lr = c[nm + "_lr"]
+        w_rel, w_share, w_v = (0.0, ""), (0.0, ""), (0.0, "")
+        # tensors whose whole gradient is mathematically zero (a conv bias in front of a norm layer, the attention f-bias): their
+        # Adam updates are a random walk of rounding noise in fp64 and fp32 alike - recognised by their second moment, skipped
+        walk = {key.split("/", 3)[3] for key in g.files if key.startswith("adam_v/%s/" % nm) and float(np.sqrt(g[key]).mean()) < 1e-6}
+        for key in g.files:
+            if key.count("/") >= 3 and key.split("/", 3)[3] in walk:
+                continue
+            if key.startswith("final/%s/" % nm):
+                _, _, stride, name = key.split("/", 3)
+                mine = sd[name].detach().double().reshape(-1)[::int(stride)].numpy()
+                ref = g[key]
+                d_ = np.abs(mine - ref)
+                w_rel = max(w_rel, (float(np.linalg.norm(mine - ref) / max(np.linalg.norm(ref), 1e-30)), name))
+                w_share = max(w_share, (float((d_ > 0.25 * lr).mean()), name))
+            elif key.startswith("adam_v/%s/" % nm):
+                _, _, stride, name = key.split("/", 3)
+                mine = opt.state[name]["v"].detach().double().reshape(-1)[::int(stride)].numpy()
+                ref = g[key]
+                w_v = max(w_v, (float(np.linalg.norm(mine - ref) / max(np.linalg.norm(ref), 1e-30)), name))
+        fin.append("%s samples: worst L2 %.1e (%s), worst share of elements off by > lr/4 %.1e (%s), worst Adam v L2 %.1e (%s)"
+                   % (nm, w_rel[0], w_rel[1], w_share[0], w_share[1], w_v[0], w_v[1]))
     first = next(k for k in au if go.is_param(k))
     fin.append("au Adam v of the first parameter (%s): norm %.1e off" % (first, abs(float(tr.au_opt.state[first]["v"].double().norm()) - meta["meta"]["au_opt_first_v_norm"])
                                                                         / meta["meta"]["au_opt_first_v_norm"]))
