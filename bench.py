@@ -180,8 +180,7 @@ def dominant_kernel_roofline(per, device):
     lib = _lib.load()
     cfg = max(per, key=lambda c: per[c]["gflop"] * (per[c]["fwd"] + per[c]["dgrad"] + per[c]["wgrad"]))
     N, H, W, Cin, Cout, K, ups, pool, fold = cfg
-    prec = ops.conv_precision()
-    sh = _lib.GimConvShape(N, H, W, Cin, Cout, K, ups, 0.2, pool, fold, 0, prec)
+    sh = _lib.GimConvShape(N, H, W, Cin, Cout, K, ups, 0.2, pool, fold, 0)
     KF = K + 1 if fold else K
     x = torch.randn(N, H >> ups, W >> ups, Cin, device=device)
     w = torch.randn(Cout, KF, KF, Cin, device=device) * 0.05     # folded layout when fold
@@ -192,10 +191,6 @@ def dominant_kernel_roofline(per, device):
     st = torch.cuda.current_stream().cuda_stream
     gf = per[cfg]["gflop"]
     dgrad = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, x.data_ptr(), dx.data_ptr(), sh, st)   # noqa: E731
-    if prec == 1 and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
-        wt = torch.empty(Cin * KF * KF * Cout, device=device)
-        lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
-        dgrad = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, x.data_ptr(), dx.data_ptr(), sh, st)   # noqa: E731
     out = {}
     for name, fn in (("fwd", lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st)),
                      ("dgrad", dgrad),
@@ -214,7 +209,7 @@ def dominant_kernel_roofline(per, device):
         out[name] = {"ms": round(ms, 4), "executed_tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
     return {"kernel": "conv N=%d %dx%d %d->%d %dx%d%s%s (%s)" % (N, H, W, Cin, Cout, K, K, ", avg-pool folded (stride-2, %dx%d taps)" % (KF, KF) if pool else "",
                                                               ", sub-pixel form of the upsampled conv" if (ups and fold) else "",
-                                                              "bf16x3 on the bf16 MFMA" if prec == 1 else "fp32 MFMA"),
+                                                              "fp32 MFMA"),
             "launches_per_step": {k_: per[cfg][k_] for k_ in ("fwd", "dgrad", "wgrad")},
             "executed_gflop_per_launch": round(gf, 2),
             "algorithmic_gflop_per_launch": round(ops.conv_algorithmic_flops(*cfg) / 1e9, 2), **out}
@@ -257,7 +252,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
-    ap.add_argument("--no-bf16x3", action="store_true", help="skip the informational second measurement on the bf16x3 matrix path")
+    ap.add_argument("--no-bf16x3", action="store_true", help="accepted and ignored (round-2 scripts): the bf16x3 matrix path was removed in round 3")
     ap.add_argument("--reg-param", type=float, default=0.0, help="R1 weight (BASELINE's metric is quoted at 0; 10 = the paper's VoxCeleb2 setting)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only: argument parsing, process group, one all-reduce, JSON line")
@@ -387,19 +382,8 @@ def main():
         torch.cuda.synchronize()
     exe_gf, algo_launch_gf, per_conv = summarize_flops(counts, _ops)
 
-    matrix_path = "bf16x3" if _ops.conv_precision() == 1 else "fp32 MFMA"
+    matrix_path = "fp32 MFMA"
     dt, dev_ms, per_step, out = timed(matrix_path)
-    # Informational second measurement, never `value`: the same K steps with the contractions on the bf16 matrix pipe by exact
-    # 3-way operand splitting (ops.set_conv_precision(1): fp32-level error, tests/test_gpu_bf16x3.py)
-    x3 = None
-    if matrix_path == "fp32 MFMA" and not args.no_bf16x3 and graphed is None and world == 1:
-        _ops.set_conv_precision(1)
-        dt3, _, _, _ = timed("bf16x3")
-        _ops.set_conv_precision(0)
-        x3 = {"value": round(B * world * args.steps / dt3, 3), "unit": "episodes/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
-              "what": "same workload and steps with gim_conv_shape.prec = 1: conv / linear forward, dgrad and wgrad on the bf16 MFMA with every "
-                      "fp32 operand split exactly into three bf16 (6 partial products, fp32 accumulate; error vs fp64 equal to the fp32 "
-                      "MFMA's or lower on every layer: profiles/r01_k_bf16x3_accuracy_vs_fp64.txt; same parity tolerances: tests/test_gpu_bf16x3.py)"}
     g_loss, d_loss = float(out[0][0]), float(out[1][0])
 
     if rank == 0:
@@ -438,8 +422,6 @@ def main():
                          "device_ms_per_step": round(dev_ms / args.steps, 3)},
             "final_losses": {"g": round(g_loss, 5), "d": round(d_loss, 5)},
         }
-        if x3 is not None:
-            line["bf16x3_path"] = x3
         if not args.no_kernel_bench:
             line["dominant_kernel"] = dominant_kernel_roofline(per_conv, device)
             log("kernel microbenchmark done")

@@ -46,15 +46,9 @@ int gim_version(void);
  *                ups = 1 the convolution of the upsampled image is computed in its sub-pixel form (4 output-parity
  *                classes, ((KH+1)/2)^2 taps each on the LOW-resolution x): same FLOP ratios as above.
  *   res_ups = 1: (forward) the residual is stored at half resolution and nearest-upsampled on the fly.
- *   prec    : matrix path of THIS call (replaces nothing in the reference: F.conv2d has one fp32 path).
- *             0 = v_mfma_f32_32x32x2_f32; 1 = "bf16x3": every fp32 operand is split exactly into three bf16 numbers and six
- *             partial products are accumulated in fp32 on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) - the fp32 result,
- *             measured closer to fp64 than path 0, at 2.67x fewer matrix-pipe cycles.  Honoured by gim_conv2d_fwd,
- *             gim_conv2d_dgrad_t and gim_conv2d_wgrad / _acc on their vector paths (channel counts that are multiples of
- *             16 / 4); other launches run path 0.
  *   tune_tile / tune_ksplit / tune_wgrad : launch overrides for tools/conv_autotune.py and the tuned-row parity tests; 0
  *             (the product's value) = the table row of this shape, else the heuristic.  tune_tile: 128 = 128x128, 641 =
- *             64x128, 1264 = 128x64, 64 = 64x64 output tile, 6432 = 64x64 with a 32-deep K step (fp32 path; forward / dgrad: channel counts that
+ *             64x128, 1264 = 128x64, 64 = 64x64 output tile, 6432 = 64x64 with a 32-deep K step (forward / dgrad: channel counts that
  *             are multiples of 32, wgrad: 32 pixels per step on the vector path; otherwise as 64), < 0 = ignore the table; tune_ksplit: split-K factor of
  *             fwd / dgrad; tune_wgrad: workgroup target of the wgrad pixel slicing.  Results never depend on them beyond
  *             the summation order.
@@ -70,7 +64,6 @@ typedef struct {
     int32_t N, H, W, Cin, Cout, KH, ups;
     float pre_slope;
     int32_t pool, wfold, res_ups;
-    int32_t prec;
     int32_t tune_tile, tune_ksplit, tune_wgrad;
     int32_t out_zeroed;
     float post_slope;
@@ -144,8 +137,8 @@ int gim_spectral_sigma_batched(const gim_sn_job* jobs, int n_jobs, const int32_t
 
 /* dgrad on TRANSPOSED weights: the input gradient of gim_conv2d_fwd as gim_conv2d_dgrad computes it (same shape struct, same
  * fused mask / 1/sigma / folds), but reading WT[Cin][KF][KF][Cout] (gim_conv2d_transpose_weights of the plain or folded
- * weights), whose rows are k-contiguous for this contraction: dgrad then runs the forward kernel's operand path, bf16x3
- * included.  Needs Cout % 16 == 0.  (F.conv2d's backward w.r.t. the input, autograd of training/gim_img_training.py:164,176.) */
+ * weights), whose rows are k-contiguous for this contraction: dgrad then runs the forward kernel's operand path (vector
+ * weight loads also when the conv has <= 8 INPUT channels: the gradient w.r.t. images).  Needs Cout % 16 == 0.  (F.conv2d's backward w.r.t. the input, autograd of training/gim_img_training.py:164,176.) */
 int gim_conv2d_transpose_weights(const float* w, float* wt, int Cout, int Cin, int KF, void* stream);
 int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, const float* mask_x, float* dx,
                        const gim_conv_shape* shape, void* stream);
@@ -153,7 +146,7 @@ int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, con
 /* Introspection (tests, tools/conv_autotune.py): the launch an entry point would make for `shape`, nothing is launched.
  *   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
  *   out[8] = {1 if a row of the compiled-in per-shape launch table matched, tile rows, tile columns, split-K factor
- *             (wgrad: pixel slices), grid x, y, z, matrix path the kernel runs (0 fp32 MFMA, 1 bf16x3)}.
+ *             (wgrad: pixel slices), grid x, y, z, 0 (one matrix path: v_mfma_f32_32x32x2_f32 / 16x16x4)}.
  * A batch beyond the 32-bit buffer-offset range (the entry points then halve it) reports the plan of its last half. */
 int gim_conv_launch_plan(const gim_conv_shape* shape, int kind, int32_t* out);
 

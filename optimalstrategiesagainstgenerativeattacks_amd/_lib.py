@@ -16,7 +16,7 @@ class GimConvShape(ctypes.Structure):
     _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("KH", c_int32), ("ups", c_int32), ("pre_slope", c_float),
                 ("pool", c_int32), ("wfold", c_int32), ("res_ups", c_int32),
-                ("prec", c_int32), ("tune_tile", c_int32), ("tune_ksplit", c_int32), ("tune_wgrad", c_int32),
+                ("tune_tile", c_int32), ("tune_ksplit", c_int32), ("tune_wgrad", c_int32),
                 ("out_zeroed", c_int32), ("post_slope", c_float)]
 
 

@@ -86,8 +86,7 @@ struct ConvP {
     int tune_ks;        // host only: split-K factor (caller's, else the tuning table's; 0 = heuristic)
     int tune_tile;      // host only: tile configuration forced by the caller (0 = table / heuristic, < 0 = heuristic only)
     int y_zeroed;       // host only: the caller guarantees y holds zeros (split-K launches then skip their memset)
-    int prec;           // host only: 1 = bf16x3 matrix path where the kernel has one
-    int tune_kind;      // host only: row kind of the launch-tuning table (0 fwd, 1 dgrad k-major, 3 fwd bf16x3, 4 dgrad on transposed weights)
+    int tune_kind;      // host only: row kind of the launch-tuning table (0 fwd, 1 dgrad k-major, 4 dgrad on transposed weights)
     float pos_inf;      // +infinity as a run-time value
     float pre_slope, mask_slope, out_scale;
     float post_slope;   // forward: leaky-relu on the stored output (1 = none; never with split-K: the slices are combined by addition)
@@ -131,38 +130,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // are not free next to MFMA (tools/micro/mfma_valu.hip: each one takes ~4 cycles from the matrix pipe).
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-
-// PREC 1 ("bf16x3"): the same fp32 contraction on the bf16 matrix pipe.  Every fp32 operand element is split EXACTLY into
-// three bf16 numbers when its tile is written to LDS (x = hi + mid + lo, truncation split of the 24-bit significand into
-// 8 + 8 + 8 bits) and six of the nine partial products are accumulated by v_mfma_f32_32x32x16_bf16 in fp32:
-// hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi; the dropped terms are <= 2^-23 |x*y|, the level of the fp32 MFMA's own
-// rounding (tools/micro/bf16x3_gemm.hip: error vs fp64 1.2e-7 against 1.4e-7 for v_mfma_f32_32x32x2_f32).  Six 32-cycle
-// MFMAs per 32x32x16 block replace eight 64-cycle ones: 2.67x fewer matrix-pipe cycles for 5.5 VALU per staged element.
-// LDS row = [hi: 16 bf16][mid][lo] + 16 B pad = 28 dwords: conflict-free ds_read_b128 / ds_write_b64.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#define X3_LDR 28
-
-// 4 consecutive-k floats -> 3 planes x 4 bf16, written as three ds_write_b64 (dst = row base + 2 * k-quad, in dwords)
-__device__ __forceinline__ void x3_split_store(unsigned* dst, const f32x4& x) {
-    unsigned r1[4], r2[4], xb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float xe = x[e];   // by value: __builtin_bit_cast of a vector-element lvalue reads element 0
-        xb[e] = __builtin_bit_cast(unsigned, xe);
-        const float d1 = xe - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);         // exact
-        r1[e] = __builtin_bit_cast(unsigned, d1);
-        const float d2 = d1 - __builtin_bit_cast(float, r1[e] & 0xFFFF0000u);         // exact, <= 8 significant bits
-        r2[e] = __builtin_bit_cast(unsigned, d2);
-    }
-    // v_perm_b32: (upper half of the second) << 16 | upper half of the first = two truncated bf16, element order kept
-    u32x2 hi = {__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
-    u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
-    u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
-    *reinterpret_cast<u32x2*>(dst) = hi;
-    *reinterpret_cast<u32x2*>(dst + 8) = mid;
-    *reinterpret_cast<u32x2*>(dst + 16) = lo;
 }
 
 // Epilogue of one accumulator block: NE values of ONE output channel `co` on rows mbase + (e & 3) + 8 * (e >> 2) (the C/D layout of
@@ -258,12 +225,10 @@ constexpr int igemm_lds_bytes(int BM, int BN, int KB, int BMODE) {
     return 2 * (BM * (KB + 4) + (BMODE == 0 ? BN * (KB + 4) : KB * BN)) * 4;
 }
 
-template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB, int PREC = 0>
-__global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 : 4)) : (igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 4 : 2)) void conv_igemm_kernel(const ConvP p) {
+template <int BM, int BN, int TM, int TN, int BMODE, int GENF, int KB>
+__global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 4 : 2) void conv_igemm_kernel(const ConvP p) {
     constexpr bool GEN = (GENF & 1) != 0;
     constexpr bool BSCALAR = (GENF & 2) != 0;
-    constexpr bool X3 = PREC == 1;
-    static_assert(!X3 || (BMODE == 0 && GENF == 0 && BN >= 32 && KB == 16), "bf16x3: k-contiguous fast path only");
     // BN == 16: narrow outputs (<= 16 channels: RGB layers, the 6-channel image pair) use the 16x16x4 MFMA - a 32-wide tile
     // would spend 81-91 % of its MFMA work on padding columns.  One wave = 32*TM rows x 16 columns = 2*TM accumulator blocks.
     constexpr bool N16 = BN == 16;
@@ -279,7 +244,7 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
     constexpr int B_U = BN / 4;                    // BMODE 1, vector: float4 units per k-row
     constexpr int B_RSTEP = 256 / B_U;
     constexpr int B_PER4 = (KB + B_RSTEP - 1) / B_RSTEP;
-    constexpr int LDA = X3 ? X3_LDR : LDK;         // dwords per k-row of an LDS tile
+    constexpr int LDA = LDK;                       // dwords per k-row of an LDS tile
     constexpr int A_SZ = BM * LDA;
     constexpr int B_SZ = (BMODE == 0) ? BN * LDA : KB * BN;
     __shared__ __attribute__((aligned(16))) float lds[2 * A_SZ + 2 * B_SZ];
@@ -370,11 +335,9 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         }
     };
 
-    // staging registers (global -> VGPR -> LDS).  bf16x3: TWO sets, loads run two K steps ahead of their LDS store (the MFMA
-    // block of a K step is 2.7x shorter than on the fp32 pipe, one step no longer covers the global-load latency)
-    constexpr int NSET = X3 ? 2 : 1;
-    f32x4 raS[NSET][A_ROWS];
-    f32x4 rb0S[NSET][B_ROWS];
+    // staging registers (global -> VGPR -> LDS)
+    f32x4 ra[A_ROWS];
+    f32x4 rb0[B_ROWS];
     float rb1[B_PER];
     f32x4 rb4[B_PER4];
 
@@ -390,10 +353,7 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         set_tap(k_ta, k_tb);
     };
 
-    auto load_tiles = [&](int k0, auto SETC) {
-        constexpr int S = decltype(SETC)::value;
-        auto& ra = raS[S];
-        auto& rb0 = rb0S[S];
+    auto load_tiles = [&](int k0) {
         if constexpr (!GEN) {
             const int ta = k_ta, tb = k_tb, c0 = k_c0;
             const int wtap = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
@@ -502,10 +462,7 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
     };
 
     const bool has_act = p.pre_slope != 1.0f;   // wave-uniform
-    auto store_tiles = [&](int buf, auto SETC) {
-        constexpr int S = decltype(SETC)::value;
-        auto& ra = raS[S];
-        auto& rb0 = rb0S[S];
+    auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             // fused leaky-relu max(x, slope*x) (slope 1 = identity), IN PLACE and branch-free: a conditional copy of the
@@ -517,18 +474,13 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.pre_slope, p.pos_inf);  // med3(x, s*x, +inf) = max(x, s*x) in 2 VALU (a literal inf folds back into the 3-op canonicalising max)
             }
-            if constexpr (X3) x3_split_store(reinterpret_cast<unsigned*>(As) + buf * A_SZ + (arow + RP * i) * LDA + (aq >> 1), ra[i]);
-            else *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
+            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
         }
         if constexpr (BMODE == 0) {
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) {
                 const int row = arow + RP * i;
-                if constexpr (X3) {
-                    if (BN % RP == 0 || row < BN) x3_split_store(reinterpret_cast<unsigned*>(Bs) + buf * B_SZ + row * LDA + (aq >> 1), rb0[i]);
-                } else {
-                    if (BN % RP == 0 || row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
-                }
+                if (BN % RP == 0 || row < BN) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + row * LDK + aq]) = rb0[i];
             }
         } else {
             if constexpr (BSCALAR) {
@@ -554,19 +506,6 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // bf16x3: the five small partial products (<= 2^-8 of the product) accumulate apart from hi*hi.  The bf16 MFMA truncates
-    // (it does not round) what falls below the accumulator's last bit when it aligns the products, a BIASED error per MFMA of up
-    // to one ulp of the accumulator; kept out of the big accumulator, five of the six MFMAs per K step truncate at the scale of
-    // a 2^-8 smaller sum.
-    f32x16 acc2[X3 ? TM : 1][X3 ? TN : 1];
-    if constexpr (X3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
-    }
     constexpr int NB16 = 2 * TM;                   // N16: 16-row accumulator blocks per wave
     const int r16 = lane & 15, q16 = lane >> 4;    // N16: row / column within a block, k quad
     f32x4 acc16[NB16];
@@ -576,26 +515,15 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
     const int nk_all = (p.Ktot + KB - 1) / KB;
     const int ks0 = kslice * p.kper;
     const int nk = min(nk_all, ks0 + p.kper);
-    using Set0 = std::integral_constant<int, 0>;
-    using Set1 = std::integral_constant<int, NSET - 1>;
     if constexpr (!GEN) seek(ks0 * KB);
-    load_tiles(ks0 * KB, Set0());
-    store_tiles(0, Set0());
-    if constexpr (X3) {
-        if (ks0 + 1 < nk) load_tiles((ks0 + 1) * KB, Set1());
-    }
+    load_tiles(ks0 * KB);
+    store_tiles(0);
     __syncthreads();
     auto kstep = [&](int ks, auto BUFC, auto MAINC) {
         constexpr int buf = decltype(BUFC)::value;   // compile-time LDS buffer: offsets fold into the ds_read / ds_write immediates
-        // MAIN: a step of the steady-state loop, whose loads and LDS stores are unconditional.  (A load under `if` makes the
-        // number of loads in flight path dependent, and the compiler then waits with the smaller count: vmcnt(2..0) instead
-        // of vmcnt(5..3) in front of the bf16x3 path's store, which drains the loads issued two steps ahead as well.)
+        // MAIN: a step of the steady-state loop, whose loads and LDS stores are unconditional
         constexpr bool MAIN = decltype(MAINC)::value;
-        if constexpr (X3) {
-            if (MAIN || ks + 2 < nk) load_tiles((ks + 2) * KB, std::integral_constant<int, buf>());   // this set's step was stored before the last barrier
-        } else {
-            if (MAIN || ks + 1 < nk) load_tiles((ks + 1) * KB, Set0());
-        }
+        if (MAIN || ks + 1 < nk) load_tiles((ks + 1) * KB);
         __builtin_amdgcn_sched_barrier(0);  // nothing that touches the staged registers may move into the MFMA block
         const float* Ab = As + buf * A_SZ;
         const float* Bb = Bs + buf * B_SZ;
@@ -618,31 +546,6 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
 #pragma unroll
                     for (int i = 0; i < NB16; ++i) acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[e], acc16[i], 0, 0, 0);
             }
-        } else if constexpr (X3) {
-            // v_mfma_f32_32x32x16_bf16: lane (r, h) feeds row r, k = 8h .. 8h+7 of each plane: one ds_read_b128 per operand plane
-            const unsigned* Au = reinterpret_cast<const unsigned*>(Ab);
-            const unsigned* Bu = reinterpret_cast<const unsigned*>(Bb);
-            bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    a[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Au + (wm0 + 32 * i + r) * LDA + 8 * pl + 4 * h));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    b[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bu + (wn0 + 32 * j + r) * LDA + 8 * pl + 4 * h));
-            }
-            // (plane of A, plane of B) per term, small terms first
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (q < 5) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[j][TB[q]], acc2[i][j], 0, 0, 0);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[j][TB[q]], acc[i][j], 0, 0, 0);
-                    }
         } else {
             // all operand fragments of the K step first, in registers of their own (with per-group arrays the compiler re-used the
             // same registers for the second half of a 32-deep step and could issue its LDS reads only after the first 8 MFMAs)
@@ -674,33 +577,19 @@ __global__ __launch_bounds__(256, PREC ? (TM * TN == 4 ? 2 : (TM * TN == 2 ? 3 :
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i][e], b[kk][j][e], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1, std::integral_constant<int, X3 ? (buf ^ 1) : 0>());
+        if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     };
     int ks = ks0;
-    if constexpr (X3) {
-        for (; ks + 3 < nk; ks += 2) {   // steady state: steps ks and ks+1 both have a step two ahead to load
-            kstep(ks, std::integral_constant<int, 0>(), std::true_type());
-            kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
-        }
-    }
-    if constexpr (!X3) {
-        for (; ks + 2 < nk; ks += 2) {   // steady state: both steps have a successor to load - no conditions around the loads / stores
-            kstep(ks, std::integral_constant<int, 0>(), std::true_type());
-            kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
-        }
+    for (; ks + 2 < nk; ks += 2) {   // steady state: both steps have a successor to load - no conditions around the loads / stores
+        kstep(ks, std::integral_constant<int, 0>(), std::true_type());
+        kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
     }
     for (; ks < nk; ks += 2) {
         kstep(ks, std::integral_constant<int, 0>(), std::false_type());
         if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>(), std::false_type());
     }
 
-    if constexpr (X3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += acc2[i][j];
-    }
     // ---- epilogue: out_scale/sigma, bias, residual, activation mask; logical pixel -> stored pixel ----
     EpiCtx ec;
     ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
@@ -805,58 +694,18 @@ __device__ __forceinline__ bool wgrad_block(const WgP& p, int& bx, int& by, int&
 // the first encoder conv still streams as float4 while its 3-channel input is gathered element by element).
 // Workgroups of the first column tile also produce the bias gradient sum_m dY[m][co] of their pixel slice from
 // the dY values they stream anyway (bias_slabs[slice][Cout]).
-// PREC 1 (bf16x3, see conv_igemm_kernel): the K dimension of this contraction is the PIXEL index, which is not contiguous for a
-// fixed channel in either NHWC operand.  The tiles stay k-major in LDS - three bf16 planes [k][channel], written without any
-// transposition (a thread's float4 = 4 channels of one pixel -> one ds_write_b64 per plane) - and the MFMA operands (8 consecutive
-// k of one channel per lane) come out of gfx950's transposing LDS read ds_read_b64_tr_b16: per 16-lane group a block of 4 k-rows x
-// 16 channels, lane 4q+p supplying the address of row q / channels 4p..4p+3, lane i receiving channel i's four k values.  Rows
-// are padded to a stride = 64 (mod 128) bytes: the 4 rows of a block then sit 16 banks apart (conflict-free, 32-lane halves).
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 lds_tr_bf16x8(const char* base, int off_lo, int off_hi) {
-    typedef __attribute__((address_space(3))) s16x4* lds_p;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off_lo));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off_hi));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-// 4 channels of one pixel -> three planes x 4 bf16 (dst = byte address of the quad in plane 0, plane stride in bytes)
-__device__ __forceinline__ void x3_split_store_planes(char* dst, int plane_bytes, const float (&x)[4]) {
-    unsigned r1[4], r2[4], xb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        xb[e] = __builtin_bit_cast(unsigned, x[e]);
-        const float d1 = x[e] - __builtin_bit_cast(float, xb[e] & 0xFFFF0000u);
-        r1[e] = __builtin_bit_cast(unsigned, d1);
-        const float d2 = d1 - __builtin_bit_cast(float, r1[e] & 0xFFFF0000u);
-        r2[e] = __builtin_bit_cast(unsigned, d2);
-    }
-    const u32x2 hi = {__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
-    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
-    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
-    *reinterpret_cast<u32x2*>(dst) = hi;
-    *reinterpret_cast<u32x2*>(dst + plane_bytes) = mid;
-    *reinterpret_cast<u32x2*>(dst + 2 * plane_bytes) = lo;
-}
-
 // WBK: pixels per K step (16; 32 for the 64x64 tile of tile code 6432 - that tile does 8 MFMAs per wave and step, so the per-step
 // costs weigh twice as much as on the larger tiles; 32 KB of LDS, still 4 workgroups per CU).
-template <int BM, int BN, int TM, int TN, int VA, int VB, bool FASTB, int PREC = 0, int WBK = BK>
-__global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP p) {
-    static_assert(!(PREC == 1) || WBK == 16, "bf16x3 wgrad: 16-pixel steps only");
+template <int BM, int BN, int TM, int TN, int VA, int VB, bool FASTB, int WBK = BK>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgP p) {
     constexpr int WAVES_N = BN / (32 * TN);
     constexpr int WAVES_M = BM / (32 * TM);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    constexpr bool X3 = PREC == 1;
-    static_assert(!X3 || (VA == 4 && VB == 4), "bf16x3 wgrad: vector path only");
     static_assert(!FASTB || VB == 4, "fast B addressing: vector path only");
     constexpr int AU = BM / VA, BU = BN / VB;                   // load units per tile row
     constexpr int A_RSTEP = 256 / AU, B_RSTEP = 256 / BU;       // tile rows covered per pass
     constexpr int A_PER = (WBK + A_RSTEP - 1) / A_RSTEP, B_PER = (WBK + B_RSTEP - 1) / B_RSTEP;
-    // bf16x3 image: bytes per k-row (stride = 64 mod 128), per plane, per buffer
-    constexpr int RSA = ((BM * 2) % 128 == 64) ? BM * 2 : BM * 2 + 64, RSB = ((BN * 2) % 128 == 64) ? BN * 2 : BN * 2 + 64;
-    constexpr int PLA = WBK * RSA, PLB = WBK * RSB;
-    constexpr int A_FLOATS = X3 ? 3 * PLA / 4 : WBK * BM, B_FLOATS = X3 ? 3 * PLB / 4 : WBK * BN;
-    static_assert(!X3 || 2 * A_FLOATS >= 256 * VA, "bias reduction scratch");
+    constexpr int A_FLOATS = WBK * BM, B_FLOATS = WBK * BN;
     __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
 
@@ -910,16 +759,13 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         }
     }
 
-    // staging registers; bf16x3: two sets, loads run two K steps ahead of their LDS store (as in conv_igemm_kernel)
-    constexpr int NSET = X3 ? 2 : 1;
-    float raS[NSET][A_PER][VA], rbS[NSET][B_PER][VB];
+    // staging registers
+    float ra[A_PER][VA], rb[B_PER][VB];
     float bsum[VA];
 #pragma unroll
     for (int e = 0; e < VA; ++e) bsum[e] = 0.f;
 
-    auto load_tiles = [&](int mb, auto SETC) {
-        auto& ra = raS[decltype(SETC)::value];
-        auto& rb = rbS[decltype(SETC)::value];
+    auto load_tiles = [&](int mb) {
         if constexpr (VA == 4) {
             const int left = mend - mb;  // > 0
             const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -982,9 +828,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     };
     // activations and the bias sums consume the loaded values here, after the MFMA block, never in load_tiles
     const bool act_a = p.a_slope != 1.0f, act_b = p.pre_slope != 1.0f;  // block-uniform
-    auto store_tiles = [&](int buf, auto SETC) {
-        auto& ra = raS[decltype(SETC)::value];
-        auto& rb = rbS[decltype(SETC)::value];
+    auto store_tiles = [&](int buf) {
         if (act_a) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
@@ -1003,19 +847,6 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
             for (int i = 0; i < B_PER; ++i)
 #pragma unroll
                 for (int e = 0; e < VB; ++e) rb[i][e] = __builtin_amdgcn_fmed3f(rb[i][e], rb[i][e] * p.pre_slope, p.pos_inf);
-        }
-        if constexpr (X3) {
-#pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int row = ak + i * A_RSTEP;
-                if (A_RSTEP * A_PER == WBK || row < WBK) x3_split_store_planes(reinterpret_cast<char*>(&As[buf][0]) + row * RSA + ac * 2, PLA, ra[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int row = bk + i * B_RSTEP;
-                if (B_RSTEP * B_PER == WBK || row < WBK) x3_split_store_planes(reinterpret_cast<char*>(&Bs[buf][0]) + row * RSB + bc * 2, PLB, rb[i]);
-            }
-            return;
         }
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
@@ -1052,75 +883,12 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
-    f32x16 acc2[X3 ? TM : 1][X3 ? TN : 1];   // bf16x3: the five small partial products (see conv_igemm_kernel)
-    if constexpr (X3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc2[i][jj][e] = 0.f;
-    }
-    // transposed-read lane offsets: k-row 8h + q, channels (wave base) + 16 * (lane bit 4) + 4p  (bytes)
-    const int tr_q = (lane >> 2) & 3, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
-    const int tr_a = (8 * h + tr_q) * RSA + (wm0 + 16 * tr_g + 4 * tr_p) * 2;
-    const int tr_b = (8 * h + tr_q) * RSB + (wn0 + 16 * tr_g + 4 * tr_p) * 2;
-
     const int nk = (mend > mbeg) ? (mend - mbeg + WBK - 1) / WBK : 0;
-    using Set0 = std::integral_constant<int, 0>;
-    using Set1 = std::integral_constant<int, NSET - 1>;
     if (nk > 0) {
-        load_tiles(mbeg, Set0());
-        store_tiles(0, Set0());
-        if constexpr (X3) {
-            if (nk > 1) load_tiles(mbeg + WBK, Set1());
-        }
+        load_tiles(mbeg);
+        store_tiles(0);
     }
     __syncthreads();
-    if constexpr (X3) {
-        auto mma = [&](int buf) {
-            const char* Ab = reinterpret_cast<const char*>(&As[buf][0]) + tr_a;
-            const char* Bb = reinterpret_cast<const char*>(&Bs[buf][0]) + tr_b;
-            bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i][pl] = lds_tr_bf16x8(Ab, pl * PLA + 64 * i, pl * PLA + 64 * i + 4 * RSA);
-#pragma unroll
-                for (int jj = 0; jj < TN; ++jj) b[jj][pl] = lds_tr_bf16x8(Bb, pl * PLB + 64 * jj, pl * PLB + 64 * jj + 4 * RSB);
-            }
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // (plane of A, plane of B), small terms first
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < TN; ++jj) {
-                        if (q < 5) acc2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[jj][TB[q]], acc2[i][jj], 0, 0, 0);
-                        else acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[jj][TB[q]], acc[i][jj], 0, 0, 0);
-                    }
-        };
-        // MAIN: steady-state step with unconditional loads / stores (a load under `if` makes the compiler wait for ALL loads)
-        auto kstep = [&](int ks, auto BUFC, auto MAINC) {
-            constexpr int buf = decltype(BUFC)::value;
-            constexpr bool MAIN = decltype(MAINC)::value;
-            if (MAIN || ks + 2 < nk) load_tiles(mbeg + (ks + 2) * WBK, std::integral_constant<int, buf>());
-            __builtin_amdgcn_sched_barrier(0);
-            mma(buf);
-            __builtin_amdgcn_sched_barrier(0);
-            if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1, std::integral_constant<int, buf ^ 1>());
-            __syncthreads();
-        };
-        int ks = 0;
-        for (; ks + 3 < nk; ks += 2) {
-            kstep(ks, std::integral_constant<int, 0>(), std::true_type());
-            kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
-        }
-        for (; ks < nk; ks += 2) {
-            kstep(ks, std::integral_constant<int, 0>(), std::false_type());
-            if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>(), std::false_type());
-        }
-    } else {
     // the LDS buffer of a step is a compile-time constant (two steps per trip): its offset folds into the ds_read / ds_write
     // immediates instead of costing address VALU next to the MFMAs (every VALU instruction is paid in matrix-pipe time)
     const float* a_rd = &As[0][0] + h * BM + wm0 + r;
@@ -1128,7 +896,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
     auto kstep32 = [&](int ks, auto BUFC, auto MAINC) {
         constexpr int buf = decltype(BUFC)::value;
         constexpr bool MAIN = decltype(MAINC)::value;   // a step of the steady-state loop: it has a successor, loads / stores unconditional
-        if (MAIN || ks + 1 < nk) load_tiles(mbeg + (ks + 1) * WBK, Set0());
+        if (MAIN || ks + 1 < nk) load_tiles(mbeg + (ks + 1) * WBK);
         __builtin_amdgcn_sched_barrier(0);  // keep every consumer of the staged registers behind the MFMA block
 #pragma unroll
         for (int kp = 0; kp < WBK / 2; ++kp) {
@@ -1144,7 +912,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1, Set0());
+        if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     };
     int ks = 0;
@@ -1157,14 +925,7 @@ __global__ __launch_bounds__(256, PREC ? 2 : 1) void conv_wgrad_kernel(const WgP
         kstep32(ks + 1, std::integral_constant<int, 1>(), std::false_type());
     }
     if (ks < nk) kstep32(ks, std::integral_constant<int, 0>(), std::false_type());
-    }
 
-    if constexpr (X3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj) acc[i][jj] += acc2[i][jj];
-    }
     // each accumulator register is two 128-byte row segments per wave: the shape float atomics run at full rate for
     float* out = p.slabs + (p.atomic ? 0 : (long long)bz * p.Cout * p.Kcols);
 #pragma unroll
@@ -1314,7 +1075,7 @@ static Geo geo_pc(const gim_conv_shape* s, int kind) {
     return g;
 }
 
-// Launch configuration.  No process-wide switches: everything a launch depends on is in its gim_conv_shape (prec, tune_*) or in
+// Launch configuration.  No process-wide switches: everything a launch depends on is in its gim_conv_shape (tune_*) or in
 // the read-only table below.  (Round 1's environment A/B switches - K step 32, XCD tile orders, channel-group K order, tile /
 // split-K forcing - were removed with the measurements recorded in DESIGN.md section 5 and profiles/r01_*.)
 //
@@ -1325,7 +1086,7 @@ static Geo geo_pc(const gim_conv_shape* s, int kind) {
 #define GIM_SMALL_TILES 24   // below this many 128x128 output tiles a launch uses 64x64 tiles (4x the workgroups, 4x shorter MFMA chain per K step)
 
 // Launch configurations measured per layer shape on an MI355X (tools/conv_autotune.py writes conv_tune_table.inc):
-// {kind (0 fwd-style, 1 dgrad-style, 2 wgrad; bf16x3 path: 3 fwd, 4 dgrad on transposed weights, 5 wgrad), M, Ca, Cb, Ktot, parity classes,
+// {kind (0 fwd-style, 1 dgrad-style, 2 wgrad, 4 dgrad on transposed weights), M, Ca, Cb, Ktot, parity classes,
 //  tile config, split-K | wgrad slice target}.
 // Shapes that are not in the table use the heuristics below.
 struct TuneEntry { int kind, M, Ca, Cb, Ktot, pc, tile, ks; };
@@ -1356,7 +1117,7 @@ static thread_local int32_t* t_plan_out = nullptr;
 // an argument error found only once the launch configuration is known (set by the launcher, returned by the entry point)
 static thread_local bool t_launch_refused = false;
 
-template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int PREC = 0, int KB = 16>
+template <int BM, int BN, int TM, int TN, int BMODE, int GEN, int KB = 16>
 static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st, bool table_hit) {
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
     const int ncls = p.g.pc ? 4 : 1;
@@ -1365,7 +1126,7 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st, bool table_hi
     p.kper = (nk + p.ksplit - 1) / p.ksplit;
     p.ksplit = (nk + p.kper - 1) / p.kper;
     if (t_plan_out) {
-        const int32_t v[8] = {table_hit ? 1 : 0, BM, BN, p.ksplit, gx, gy, p.ksplit * ncls, PREC};
+        const int32_t v[8] = {table_hit ? 1 : 0, BM, BN, p.ksplit, gx, gy, p.ksplit * ncls, 0};
         for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
         return;
     }
@@ -1375,17 +1136,11 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st, bool table_hi
         return;
     }
     if (p.ksplit > 1 && !p.y_zeroed) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB, PREC>), dim3(gx, gy, p.ksplit * ncls), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, TM, TN, BMODE, GEN, KB>), dim3(gx, gy, p.ksplit * ncls), dim3(256), 0, st, p);
 }
 
 template <int BM, int BN, int TM, int TN, int BMODE, int GEN>
 static void launch_cfg(const ConvP& p, size_t y_elems, hipStream_t st, bool table_hit) {
-    if constexpr (BMODE == 0 && GEN == 0 && BN >= 32) {
-        if (p.prec == 1) {
-            launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN, 1>(p, y_elems, st, table_hit);
-            return;
-        }
-    }
     launch_cfg_kb<BM, BN, TM, TN, BMODE, GEN>(p, y_elems, st, table_hit);
 }
 
@@ -1395,8 +1150,8 @@ static void launch_cfg(const ConvP& p, size_t y_elems, hipStream_t st, bool tabl
 template <int BMODE, int GEN>
 static void launch_64x64(const ConvP& p, size_t y_elems, hipStream_t st, bool table_hit, bool kb32) {
     if constexpr (GEN == 0) {
-        if (kb32 && p.prec == 0 && p.Ca % 32 == 0) {
-            launch_cfg_kb<64, 64, 1, 1, BMODE, GEN, 0, 32>(p, y_elems, st, table_hit);
+        if (kb32 && p.Ca % 32 == 0) {
+            launch_cfg_kb<64, 64, 1, 1, BMODE, GEN, 32>(p, y_elems, st, table_hit);
             return;
         }
     }
@@ -1433,16 +1188,10 @@ static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     }
 }
 
-static int check_prec(const gim_conv_shape* s) {
-    GIM_CHECK_ARG(s->prec == 0 || s->prec == 1, "conv: prec must be 0 (fp32 MFMA) or 1 (bf16x3)");
-    return GIM_OK;
-}
-
 extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias, const float* sigma, const float* residual,
                               float* y, const gim_conv_shape* s, void* stream) {
     int rc = check_shape(s);
     if (rc) return rc;
-    if ((rc = check_prec(s))) return rc;
     GIM_CHECK_ARG(x && w && y, "conv fwd: null pointer");
     {   // operands beyond the 32-bit buffer-offset range: halve the batch (images are independent)
         const size_t xi = (size_t)(s->H >> s->ups) * (s->W >> s->ups) * s->Cin;        // elements per image
@@ -1472,8 +1221,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     p.pre_slope = s->pre_slope; p.mask_slope = 1.f; p.out_scale = s->pool ? 0.25f : 1.f; p.res_ups = s->res_ups;
     GIM_CHECK_ARG(s->post_slope >= 0.f && s->post_slope <= 1.f, "conv fwd: post_slope must be in [0, 1] (0 or 1 = none)");
     p.post_slope = (s->post_slope > 0.f) ? s->post_slope : 1.f;
-    p.prec = s->prec;
-    p.tune_kind = s->prec == 1 ? 3 : 0;
+    p.tune_kind = 0;
     p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit; p.y_zeroed = s->out_zeroed;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
@@ -1490,7 +1238,6 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
                       const gim_conv_shape* s, void* stream, bool transposed) {
     int rc = check_shape(s);
     if (rc) return rc;
-    if ((rc = check_prec(s))) return rc;
     GIM_CHECK_ARG(dy && w && dx, "conv dgrad: null pointer");
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(mask_x && s->ups && !up_fold), "conv dgrad: mask_x with ups == 1 needs folded weights");
@@ -1532,7 +1279,6 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
         // WT[ci][a][b][co]: the weight rows are k-contiguous (k = (tap, co)), i.e. the forward kernel's operand layout
         GIM_CHECK_ARG(!gen && !((uintptr_t)w & 15), "conv dgrad (transposed weights): Cout % 16 == 0 and 16-byte aligned operands required");
         p.Cin_w = s->Cout;
-        p.prec = s->prec;
         p.tune_kind = 4;
         launch_igemm<0, 0>(p, y_elems, st);
         if (t_plan_out) return GIM_OK;
@@ -1573,8 +1319,7 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     int tile = s->tune_tile > 0 ? s->tune_tile : 0;
     if (!target && !tile && s->tune_tile == 0) {
         const int pcw = (s->pool ? 1 : 0) + (up_fold ? 2 : 0);
-        const TuneEntry* te = s->prec == 1 ? tune_lookup(5, (int)M, q.rows, q.cols, s->KH, pcw) : nullptr;   // bf16x3 rows first
-        if (!te) te = tune_lookup(2, (int)M, q.rows, q.cols, s->KH, pcw);
+        const TuneEntry* te = tune_lookup(2, (int)M, q.rows, q.cols, s->KH, pcw);
         if (te) { target = te->ks; tile = te->tile; q.table_hit = 1; }
     }
     q.bm = q.rows > 64 ? 128 : (q.rows > 32 ? 64 : 32);
@@ -1585,7 +1330,7 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     else if (tile == 64 || tile == 6432) { q.bm = 64; q.bn = 64; }
     else if (tile == 32128) { q.bm = 32; q.bn = 128; }
     // 32-pixel K steps: fp32 path, both operands on 16-byte loads (the launcher falls back to 16 otherwise)
-    q.bk = (tile == 6432 && s->prec == 0 && q.rows % 4 == 0 && (up_fold ? s->Cout : s->Cin) % 4 == 0) ? 32 : BK;
+    q.bk = (tile == 6432 && q.rows % 4 == 0 && (up_fold ? s->Cout : s->Cin) % 4 == 0) ? 32 : BK;
     const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
     // Heuristic: about four workgroups per CU in total and at least 32 K-steps (512 pixels) per workgroup, so that the float
     // atomics of the combine stay small next to the MFMA work - unless that leaves most CUs idle (1x1 convs and linears on small
@@ -1620,20 +1365,11 @@ extern "C" int gim_conv2d_wgrad_slabs(const gim_conv_shape* s) {
     return wgrad_plan(s).ns;
 }
 
-template <bool FASTB>
-static void launch_wgrad_x3(const WgP& p, int bm, int bn, dim3 g, hipStream_t st) {
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 1, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1, 2, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, 4, 4, FASTB, 1>), g, dim3(256), 0, st, p);
-}
-
 template <int VA, int VB, bool FASTB>
 static void launch_wgrad(const WgP& p, int bm, int bn, int bk, dim3 g, hipStream_t st) {
     if constexpr (VA == 4 && VB == 4) {
         if (bk == 32 && bm == 64 && bn == 64) {
-            hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, 4, 4, FASTB, 0, 32>), g, dim3(256), 0, st, p);
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, 1, 4, 4, FASTB, 32>), g, dim3(256), 0, st, p);
             return;
         }
     }
@@ -1650,7 +1386,6 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
                       void* stream, bool prezeroed) {
     int rc = check_shape(s);
     if (rc) return rc;
-    if ((rc = check_prec(s))) return rc;
     GIM_CHECK_ARG(dy && x && slabs, "conv wgrad: null pointer");
     const WgPlan q = wgrad_plan(s);
     const bool atomic = prezeroed ? true : (n_slabs == 1 && q.ns > 1);
@@ -1683,21 +1418,17 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     p.xcd = (q.ns >= 64 || (q.ns >= 8 && q.ns % 8 == 0)) ? 1 : 0;   // every XCD gets (nearly) the same number of slices
     dim3 g((q.cols + q.bn - 1) / q.bn, (q.rows + q.bm - 1) / q.bm, p.xcd ? (q.ns + 7) / 8 * 8 : q.ns);   // z padded: wgrad_block
     if (t_plan_out) {
-        const int32_t v[8] = {q.table_hit, q.bm, q.bn, q.ns, (int32_t)g.x, (int32_t)g.y, (int32_t)g.z, s->prec};
+        const int32_t v[8] = {q.table_hit, q.bm, q.bn, q.ns, (int32_t)g.x, (int32_t)g.y, (int32_t)g.z, 0};
         for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
         return GIM_OK;
     }
     // per operand as the kernel sees it (the sub-pixel form swaps the roles): A = p.dy with p.Cout channels, B = p.x with p.Cin
     const bool va = (p.Cout % 4 == 0) && !((uintptr_t)p.dy & 15);
     const bool vb = (p.Cin % 4 == 0) && !((uintptr_t)p.x & 15);
-    const int bk = (q.bk == 32 && va && vb && s->prec == 0) ? 32 : BK;
+    const int bk = (q.bk == 32 && va && vb) ? 32 : BK;
     const bool fastb = vb && p.g.ups == 0 && ((p.g.H * p.g.W) & (bk - 1)) == 0;   // a K step stays inside one image
     hipStream_t st = (hipStream_t)stream;
-    if (s->prec == 1 && va && vb) {
-        if (fastb) launch_wgrad_x3<true>(p, q.bm, q.bn, g, st);
-        else launch_wgrad_x3<false>(p, q.bm, q.bn, g, st);
-    }
-    else if (va && fastb) launch_wgrad<4, 4, true>(p, q.bm, q.bn, bk, g, st);
+    if (va && fastb) launch_wgrad<4, 4, true>(p, q.bm, q.bn, bk, g, st);
     else if (va && vb) launch_wgrad<4, 4, false>(p, q.bm, q.bn, bk, g, st);
     else if (va) launch_wgrad<4, 1, false>(p, q.bm, q.bn, bk, g, st);
     else if (vb) launch_wgrad<1, 4, false>(p, q.bm, q.bn, bk, g, st);
@@ -1728,7 +1459,7 @@ extern "C" int gim_conv2d_wgrad_acc(const float* dy, const float* x, float* acc,
 // The launch a conv entry point would make for `shape`, without launching anything (tests, tools/conv_autotune.py).
 //   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
 //   out[8] = {1 if a row of the compiled-in launch table matched this shape, tile rows BM, tile columns BN,
-//             split-K factor (wgrad: pixel slices), grid x, grid y, grid z, matrix path the kernel runs (0 fp32 MFMA, 1 bf16x3)}
+//             split-K factor (wgrad: pixel slices), grid x, grid y, grid z, 0 (one matrix path: the fp32 MFMA)}
 extern "C" int gim_conv_launch_plan(const gim_conv_shape* s, int kind, int32_t* out) {
     GIM_CHECK_ARG(s && out && kind >= 0 && kind <= 3, "conv_launch_plan: bad args");
     float* const fake = reinterpret_cast<float*>(uintptr_t(4096));   // aligned, never dereferenced: nothing is launched

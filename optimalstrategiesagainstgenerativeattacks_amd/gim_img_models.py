@@ -48,15 +48,11 @@ def _use_side_streams(t):
 # hardware queues, with or without RCCL.
 _STREAM_MAP = [int(v) for v in os.environ.get("GIM_STREAM_MAP", "0,1,2,2,0").split(",")]
 assert len(_STREAM_MAP) == 5, "GIM_STREAM_MAP: five comma-separated stream ids (roles 0..4)"
-# The bf16x3 matrix path runs at the board's power limit and gains nothing from a second stream inside lane 1: with lane 1 on ONE
-# stream it is 1-2 % faster in alternating runs (468 / 461 / 454 against 458 / 455 / 451 episodes/s on one box; 439.8 vs 414.5 in
-# profiles/r02_stream_map_sweep_final_build.txt); the fp32 path keeps the map above.
-_STREAM_MAP_X3 = _STREAM_MAP if "GIM_STREAM_MAP" in os.environ else [0, 1, 2, 2, 2]
 _POOL = {}
 
 
 def _role_stream(device, role):
-    key = (device.type, device.index, (_STREAM_MAP_X3 if ops.conv_precision() == 1 else _STREAM_MAP)[role])
+    key = (device.type, device.index, _STREAM_MAP[role])
     if key not in _POOL:
         _POOL[key] = torch.cuda.Stream(device=device)
     return _POOL[key]

@@ -43,7 +43,7 @@ class GraphedGimStep:
         for opt in (self.mod.impersonator_opt, self.mod.authenticator_opt):
             opt.note_steps(-1)
         # With the counters restored, the caches of tensors derived from the weights (folded weights per conv, transposed weights
-        # of the bf16x3 dgrad) carry the keys of tensors that the capture only RECORDED, never computed: an eager forward before
+        # of the image-gradient dgrad) carry the keys of tensors that the capture only RECORDED, never computed: an eager forward before
         # the first replay would read them.  Drop them (the graph keeps its own references and recomputes them on every replay).
         from . import model_blocks as mb
         from . import ops

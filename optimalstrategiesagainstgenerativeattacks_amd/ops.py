@@ -119,28 +119,12 @@ def weight_phys(w):
     return wp if wp.is_contiguous() else wp.contiguous()
 
 
-# Matrix path of the conv / linear contractions: 0 = fp32 MFMA, 1 = bf16x3 (include/gim_hip.h, gim_conv_shape.prec).  A host-side
-# default that every launch copies into its shape struct (the library itself keeps no state); GIM_CONV_PREC sets the start value.
-_CONV_PREC = [1 if os.environ.get("GIM_CONV_PREC") == "1" else 0]
 # Deterministic weight-gradient combine (slabs + fixed-order reduce) instead of float atomics, for the non-queued path
 _WGRAD_SLABS = os.environ.get("GIM_WGRAD_SLABS") is not None
 
 
-def conv_precision():
-    return _CONV_PREC[0]
-
-
-def set_conv_precision(mode):
-    """Select the matrix path of all following conv / linear launches of this process; returns the previous mode."""
-    if mode not in (0, 1):
-        raise ValueError("conv precision must be 0 (fp32 MFMA) or 1 (bf16x3)")
-    prev = _CONV_PREC[0]
-    _CONV_PREC[0] = mode
-    return prev
-
-
 def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
-    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, _CONV_PREC[0], 0, 0, 0, 0)
+    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, 0, 0, 0, 0)
 
 
 # Outputs of split-K launches.  A layer whose output tiles do not fill the chip is sliced along K over the grid and its slices
@@ -156,7 +140,7 @@ _ZERO_PAGE = 16 << 20   # floats per page (64 MB)
 
 def _splits_k(sh, plan_kind, key):
     """Does this launch combine K slices with atomics (and so need a zeroed output)?"""
-    k_ = (plan_kind, sh.prec) + key
+    k_ = (plan_kind,) + key
     v = _SPLITS_K.get(k_)
     if v is None:
         out = (ctypes.c_int32 * 8)()
@@ -533,8 +517,8 @@ def _transposed(lib, w, wk, Cout, Cin, KF):
 
 def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
     """dx = lrelu'(x) * dgrad(dy, w) / sigma  (through the pool / sub-pixel folds when the forward used them).
-    With the bf16x3 matrix path selected (sh.prec == 1, ops.set_conv_precision) and the parameter `w` given, layers with Cout % 16 == 0 run
-    the k-contiguous kernel on cached transposed weights (gim_conv2d_dgrad_t)."""
+    With the parameter `w` given, the gradient w.r.t. IMAGES (Cin <= 8, Cout % 16 == 0) runs the k-contiguous kernel on cached
+    transposed weights (gim_conv2d_dgrad_t)."""
     N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
     if _FLOPS is not None:
         _note_conv("dgrad", cfg)
@@ -542,9 +526,9 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
     key = (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold)
     wk = wf if fold else wp
     # dgrad on cached transposed weights WT[Cin][KF][KF][Cout] (rows k-contiguous: the forward kernel's operand path, vector weight
-    # loads): on the bf16x3 path for the 16-multiple layers, and - on either path - for the gradient w.r.t. IMAGES (<= 8 input
+    # loads) for the gradient w.r.t. IMAGES (<= 8 input
     # channels: 3 / 6 / 1), where the k-major kernel falls back to scalar weight loads (output channels not a multiple of 4)
-    if w is not None and Cout % 16 == 0 and not (ups and not fold) and ((sh.prec == 1 and Cin >= 32) or (Cin <= 8 and _NARROW_DGRAD_T)):
+    if w is not None and Cout % 16 == 0 and not (ups and not fold) and Cin <= 8 and _NARROW_DGRAD_T:
         wt = _transposed(lib, w, wk, Cout, Cin, KH + 1 if fold else KH)
         dx = _conv_out(sh, 2, key, tuple(x.shape), x.device)
         check(lib.gim_conv2d_dgrad_t(_p(dy), _p(wt), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad_t")

@@ -308,7 +308,7 @@ def _assert_final_state(mod, ref, walk, what, rel=3e-4):
 def test_config5_as_stated_m5_n20_k20_vs_reference_golden():
     """BASELINE config 5 at its stated set sizes: 128x128x3, m = 5 leaked, n = 20 generated, k = 20 registration images, one
     episode (models/gim_img_models.py:364-423 with m > 1, models/gim_basic_models.py:152-172 with 20-image sets), reference run
-    in fp64.  The engine computes in fp32 storage (fp32 MFMA, or bf16x3 at fp32 accuracy): DESIGN.md section 8."""
+    in fp64.  The engine computes in fp32 storage (fp32 MFMA): DESIGN.md section 8."""
     _check_nets("vox128_m5n20k20", "128_3_512", 1e-3, 5e-2)
 
 
@@ -1167,7 +1167,7 @@ def test_bench_two_ranks_non_dry_on_one_card():
     env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(GIM_BENCH_BACKEND="gloo", GIM_BENCH_ONE_DEVICE="1")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
-                        "--no-cpu-baseline", "--no-kernel-bench", "--no-traffic", "--no-bf16x3"],
+                        "--no-cpu-baseline", "--no-kernel-bench", "--no-traffic"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -6,8 +6,7 @@ on the kernel-level problem size (M = images x pixels, channels, K), so the smal
 them.  This file walks EVERY distinct convolution shape of the table and runs forward, input gradient and weight / bias
 gradient through the product's autograd operator (``ops.conv2d``: the same C-ABI calls, shape struct and queued
 weight-gradient path as a training step; the launch-override fields of the shape stay 0, so the table row is what
-launches), on the fp32 MFMA and - where the table holds bf16x3 rows (kinds 3 / 4 / 5) - with ``ops.set_conv_precision(1)``,
-and compares ELEMENTWISE with torch's own fp64 ``F.conv2d`` autograd of the unfused reference form
+launches), and compares ELEMENTWISE with torch's own fp64 ``F.conv2d`` autograd of the unfused reference form
 ``avg_pool2d(conv2d(upsample(leaky_relu(x)), w) + b)``  (models/model_blocks.py:497-514, 752-773, 842-865).
 
 The CPU part (``-m "not gpu"``) checks with ``gim_conv_launch_plan`` that every row of the table is reachable: the shape in
@@ -48,10 +47,10 @@ ROWS = parse_table()
 SHAPES = sorted({r[9] for r in ROWS})
 
 
-def _plan(lib, cfg, api_kind, prec):
+def _plan(lib, cfg, api_kind):
     from optimalstrategiesagainstgenerativeattacks_amd import _lib
     N, H, W, Cin, Cout, K, ups, slope, pool, fold = cfg
-    sh = _lib.GimConvShape(N, H, W, Cin, Cout, K, ups, slope, pool, fold, 0, prec)
+    sh = _lib.GimConvShape(N, H, W, Cin, Cout, K, ups, slope, pool, fold, 0)
     out = (ctypes.c_int32 * 8)()
     assert lib.gim_conv_launch_plan(sh, api_kind, ctypes.cast(out, ctypes.c_void_p)) == 0, lib.gim_last_error()
     return list(out)
@@ -59,21 +58,21 @@ def _plan(lib, cfg, api_kind, prec):
 
 def test_table_parses_and_is_not_empty():
     assert len(ROWS) > 100 and len(SHAPES) > 40
-    assert {r[0] for r in ROWS} <= {0, 1, 2, 3, 4, 5}
+    assert {r[0] for r in ROWS} <= {0, 1, 2, 4}
 
 
 def test_every_table_row_is_reachable_from_its_shape():
     """The launcher, given the layer shape in a row's comment, finds that row (table kind -> entry point / matrix path:
-    0 fwd, 1 dgrad on k-major weights, 2 wgrad on the fp32 MFMA; 3 fwd, 4 dgrad on transposed weights, 5 wgrad on bf16x3) and
+    0 fwd, 1 dgrad on k-major weights, 2 wgrad, 4 dgrad on transposed weights) and
     launches its tile / split.  No GPU needed: gim_conv_launch_plan launches nothing."""
     from optimalstrategiesagainstgenerativeattacks_amd import _lib
     lib = _lib.load()
-    api = {0: (0, 0), 1: (1, 0), 2: (3, 0), 3: (0, 1), 4: (2, 1), 5: (3, 1)}   # table kind -> (plan kind, prec)
+    api = {0: 0, 1: 1, 2: 3, 4: 2}   # table kind -> plan kind (entry point)
     tiles = {128: (128, 128), 641: (64, 128), 1264: (128, 64), 64: (64, 64), 6432: (64, 64)}
     for kind, M, Ca, Cb, Ktot, pc, tile, ks, name, cfg in ROWS:
-        plan = _plan(lib, cfg, *api[kind])
+        plan = _plan(lib, cfg, api[kind])
         assert plan[0] == 1, ("row not found by its own shape", kind, name, cfg, plan)
-        if kind in (2, 5):
+        if kind == 2:
             continue   # wgrad rows carry a workgroup target, not a tile
         if tile:
             assert tuple(plan[1:3]) == tiles[tile], (kind, name, cfg, plan, tile)
@@ -149,30 +148,25 @@ def test_tuned_shape_elementwise_vs_fp64_conv2d(cfg):
     b = torch.randn(Cout, device=dev, generator=g)
     dy = torch.rand(N, H >> pool, W >> pool, Cout, device=dev, generator=g) * 2 - 1
     y_r, dx_r, dw_r, db_r = _reference(x, w, b, dy, cfg, _ref_device())
-    for prec in ([0] if kinds & {0, 1, 2} else []) + ([1] if kinds & {3, 4, 5} else []):
-        # the launches below must be the table's: ask the launcher (same shape struct the operator builds)
-        api = {0: 0, 1: 1, 2: 3} if prec == 0 else {3: 0, 4: 2, 5: 3}      # table kind -> entry point of gim_conv_launch_plan
-        for k in kinds & set(api):
-            assert _plan(lib, cfg, api[k], prec)[0] == 1, ("table row not in force", k, cfg)
-        prev = ops.set_conv_precision(prec)
-        try:
-            xg = x.clone().requires_grad_()
-            wg = w.permute(0, 3, 1, 2).detach().requires_grad_()          # logical [Cout,Cin,K,K], channels-last storage
-            assert wg.permute(0, 2, 3, 1).is_contiguous()
-            bg = b.clone().requires_grad_()
-            # .grad buffers in the weights' own memory order, as FusedAdam's flat gradient bucket provides them: the backward
-            # then takes the queued path of a training step (gim_conv2d_wgrad_acc into an arena + batched finish)
-            wg.grad = torch.zeros_like(wg)
-            bg.grad = torch.zeros_like(bg)
-            # sigma = 1 with u = v = 0: the spectral-norm chain rule of the finish runs (as for every conv of the engine) and
-            # adds nothing, so the reference stays the plain convolution
-            sg, u0, v0 = torch.ones(1, device=dev), torch.zeros(Cout, device=dev), torch.zeros(Cin * K * K, device=dev)
-            yg = ops.conv2d(xg, wg, bg, None, sg, u0, v0, ups, slope, pool=bool(pool))
-            _close(yg, y_r, "forward (prec %d)" % prec)
-            yg.backward(dy)
-            torch.cuda.synchronize()
-            _close(xg.grad, dx_r, "input gradient (prec %d)" % prec)
-            _close(wg.grad.permute(0, 2, 3, 1), dw_r, "weight gradient (prec %d)" % prec)
-            _close(bg.grad, db_r, "bias gradient (prec %d)" % prec)
-        finally:
-            ops.set_conv_precision(prev)
+    # the launches below must be the table's: ask the launcher (same shape struct the operator builds)
+    api = {0: 0, 1: 1, 2: 3, 4: 2}      # table kind -> entry point of gim_conv_launch_plan
+    for k in kinds & set(api):
+        assert _plan(lib, cfg, api[k])[0] == 1, ("table row not in force", k, cfg)
+    xg = x.clone().requires_grad_()
+    wg = w.permute(0, 3, 1, 2).detach().requires_grad_()          # logical [Cout,Cin,K,K], channels-last storage
+    assert wg.permute(0, 2, 3, 1).is_contiguous()
+    bg = b.clone().requires_grad_()
+    # .grad buffers in the weights' own memory order, as FusedAdam's flat gradient bucket provides them: the backward
+    # then takes the queued path of a training step (gim_conv2d_wgrad_acc into an arena + batched finish)
+    wg.grad = torch.zeros_like(wg)
+    bg.grad = torch.zeros_like(bg)
+    # sigma = 1 with u = v = 0: the spectral-norm chain rule of the finish runs (as for every conv of the engine) and
+    # adds nothing, so the reference stays the plain convolution
+    sg, u0, v0 = torch.ones(1, device=dev), torch.zeros(Cout, device=dev), torch.zeros(Cin * K * K, device=dev)
+    yg = ops.conv2d(xg, wg, bg, None, sg, u0, v0, ups, slope, pool=bool(pool))
+    _close(yg, y_r, "forward")
+    yg.backward(dy)
+    torch.cuda.synchronize()
+    _close(xg.grad, dx_r, "input gradient")
+    _close(wg.grad.permute(0, 2, 3, 1), dw_r, "weight gradient")
+    _close(bg.grad, db_r, "bias gradient")

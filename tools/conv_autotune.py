@@ -76,10 +76,9 @@ def main():
         narrow = bool(Cin % 16 or Cout % 16)   # generic-K layers (3 / 6 channels): forward / dgrad use the heuristics, wgrad is tuned
         n_dx = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dx)
         n_dw = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dw)
-        x3 = ops.conv_precision() == 1      # bf16x3 matrix path: its own table rows (kinds 3, 4, 5)
 
         def shape(tile=-1, ks=0, tg=0):   # tile -1: heuristics only (ignore the rows already in the compiled-in table)
-            return _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0, 1 if x3 else 0, tile, ks, tg)
+            return _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0, tile, ks, tg)
         sh = shape()
         x = torch.randn(N, H >> ups, W >> ups, Cin, device=dev)
         KF = KH + 1 if fold else KH
@@ -105,30 +104,21 @@ def main():
         Mw = N * (H >> (1 if fold else 0)) * (W >> (1 if fold else 0))
         keys["wgrad"] = (2, Mw, rows, cols, KH, (1 if pool else 0) + (2 if up_fold else 0))
         dgrad_fn = lambda sh_: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh_, st)   # noqa: E731
-        if x3:
-            keys["fwd"] = (3,) + keys["fwd"][1:]
-            if Cin % 4 == 0 and Cout % 4 == 0:
-                keys["wgrad"] = (5,) + keys["wgrad"][1:]
-            if Cin >= 32 and not (ups and not fold):   # as ops._conv_dgrad
-                wt = torch.empty(Cin * KF * KF * Cout, device=dev)
-                lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
-                keys["dgrad"] = (4,) + keys["dgrad"][1:]
-                dgrad_fn = lambda sh_: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh_, st)   # noqa: E731
         runs = {"fwd": (cnt, lambda sh_: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh_, st)),
                 "dgrad": (n_dx, dgrad_fn),
                 "wgrad": (n_dw, lambda sh_: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh_, st))}
         for kind, (calls, fn) in runs.items():
-            if not calls or (x3 and keys[kind][0] < 3) or kind not in args.kinds.split(",") or (narrow and kind != "wgrad"):   # bf16x3 pass: only its own rows (kinds 3, 4, 5)
+            if not calls or kind not in args.kinds.split(",") or (narrow and kind != "wgrad"):
                 continue
             Cb = keys[kind][3]
             t_auto = time_ms(lambda: fn(sh))
             best = (t_auto, 0, 0)
             if kind == "wgrad":   # output tile x workgroup target of the pixel slicing (an explicit target lifts the 512-pixel floor)
-                cands = [(tl, 0, tg) for tl in (0, 128, 641, 1264, 64) + (() if x3 else (6432,)) for tg in (128, 256, 512, 1024, 2048, 4096, 8192)]
+                cands = [(tl, 0, tg) for tl in (0, 128, 641, 1264, 64, 6432) for tg in (128, 256, 512, 1024, 2048, 4096, 8192)]
             else:
                 tiles = [128, 641, 1264, 64] if Cb > 64 else ([1264, 64] if Cb > 32 else [])
-                if tiles and not x3 and keys[kind][2] % 32 == 0:
-                    tiles.append(6432)   # 64x64 tile with a 32-deep K step (fp32 path only)
+                if tiles and keys[kind][2] % 32 == 0:
+                    tiles.append(6432)   # 64x64 tile with a 32-deep K step
                 cands = [(tl, ks, 0) for tl in tiles for ks in (1, 2, 3, 4, 6, 8)]
             for tl, ks, tg in cands:
                 shc = shape(tl if tl else -1, ks, tg)

@@ -66,8 +66,7 @@ def main():
         N, H, W, Cin, Cout, KH, ups, slope, pool, fold = cfg
         n_dx = sum(c for (cf, dx, dw), c in bwd_calls.items() if cf == cfg and dx)
         n_dw = sum(c for (cf, dx, dw), c in bwd_calls.items() if cf == cfg and dw)
-        prec = ops.conv_precision()
-        sh = _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0, prec)
+        sh = _lib.GimConvShape(N, H, W, Cin, Cout, KH, ups, slope, pool, fold, 0)
         x = torch.randn(N, H >> ups, W >> ups, Cin, device=dev)
         KF = KH + 1 if fold else KH
         w = torch.randn(Cout, KF, KF, Cin, device=dev) * 0.05   # folded layout when fold
@@ -79,7 +78,7 @@ def main():
         flops = ops.conv_executed_flops(N, H, W, Cin, Cout, KH, ups, pool, fold)      # what the kernels execute (folds!)
         algo = ops.conv_algorithmic_flops(N, H, W, Cin, Cout, KH)                      # the unfused reference op
         t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
-        if Cout % 16 == 0 and not (ups and not fold) and ((prec == 1 and Cin >= 32) or Cin <= 8):   # as ops._conv_dgrad
+        if Cout % 16 == 0 and not (ups and not fold) and Cin <= 8:   # as ops._conv_dgrad
             wt = torch.empty(Cin * KF * KF * Cout, device=dev)
             lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
             t_d = time_ms(lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0

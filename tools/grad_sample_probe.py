@@ -1,6 +1,6 @@
 """Engine vs the reference's gradient-tensor samples (tests/golden/nets_<tag>_grads.npz) at the benchmark shapes, per tensor: relative
 error, and the same after fitting one scalar (a common factor would point at a loss-side scale, scattered values at rounding noise).
-    python tools/grad_sample_probe.py [prec=0|1]"""
+    python tools/grad_sample_probe.py"""
 import os
 import sys
 import tempfile
@@ -15,7 +15,6 @@ from optimalstrategiesagainstgenerativeattacks_amd import ops  # noqa: E402
 from tests.helpers import episode, load_json, load_npz, relerr  # noqa: E402
 from tests.test_gpu_models import _product_models, dev  # noqa: E402
 
-ops.set_conv_precision(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 for tag, cfg in (("om32_f64", "32_1_512"), ("vox64_f64", "64_3_512")):
     g = load_npz("nets_%s.npz" % tag)
@@ -30,7 +29,7 @@ for tag, cfg in (("om32_f64", "32_1_512"), ("vox64_f64", "64_3_512")):
         tr.impersonator_opt.zero_grad()
         loss, fake, out = tr.forward(mode="impersonator_forward", leaked_sample=leaked, si_sample=si, z=z)
         loss.mean().backward()
-        print("%s run %d (matrix path %d): G loss %.2e, logits %.2e, fake %.2e" % (tag, rep, ops.conv_precision(), relerr(loss, g["g/loss"]),
+        print("%s run %d: G loss %.2e, logits %.2e, fake %.2e" % (tag, rep, relerr(loss, g["g/loss"]),
                                                                                    relerr(out, g["g/out"]), relerr(fake[:g["g/fake"].shape[0], :g["g/fake"].shape[1]], g["g/fake"])))
         params = dict(im.named_parameters())
         for k in gs.files:

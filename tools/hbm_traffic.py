@@ -31,7 +31,7 @@ def main():
     top = sorted(fk.items(), key=lambda kv: -kv[1])[:8]
     print(json.dumps({
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-                   "--no-cpu-baseline --no-kernel-bench --no-bf16x3  (tools/measure_round.sh)",
+                   "--no-cpu-baseline --no-kernel-bench  (tools/measure_round.sh)",
         "workload": "%s B=%d" % (workload, B), "steps_in_run": steps,
         "fetch_size_kb_raw": fetch, "write_size_kb_raw": write,
         "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B), WRITE_SIZE exact; includes model construction kernels, "

@@ -1,8 +1,8 @@
 """Launch ONE convolution shape repeatedly through the C ABI (for rocprofv3 --pmc / --kernel-trace runs).
 
-    python tools/kernel_probe.py fwd|dgrad|wgrad N H Cin Cout K [ups] [reps] [pool] [prec] [tile] [ksplit|wgrad target]
+    python tools/kernel_probe.py fwd|dgrad|wgrad N H Cin Cout K [ups] [reps] [pool] [0] [tile] [ksplit|wgrad target]
 
-pool = 1 (or ups = 1 with K > 1): the folded form the engine launches for that layer.  prec 1 = bf16x3.  tile / ksplit:
+pool = 1 (or ups = 1 with K > 1): the folded form the engine launches for that layer.  (argument 10 is unused: it selected the removed bf16x3 path).  tile / ksplit:
 launch overrides (gim_conv_shape.tune_*; 0 = table / heuristic, tile < 0 = heuristic only).
 """
 import ctypes
@@ -25,7 +25,7 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
     slope = float(os.environ.get("PROBE_SLOPE", "0.2"))   # pre-activation slope (1.0 = none)
-    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, slope, pool, fold, 0, prec, tile, 0 if kind == "wgrad" else ks, ks if kind == "wgrad" else 0)
+    sh = _lib.GimConvShape(N, H, H, Cin, Cout, K, ups, slope, pool, fold, 0, tile, 0 if kind == "wgrad" else ks, ks if kind == "wgrad" else 0)
     KF = K + 1 if fold else K
     x = torch.randn(N, H >> ups, H >> ups, Cin, device=dev)
     w = torch.randn(Cout, KF, KF, Cin, device=dev) * 0.05
@@ -36,7 +36,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     dgrad = lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
     plan_kind = {"fwd": 0, "dgrad": 1, "wgrad": 3}[kind]
-    if prec == 1 and Cout % 16 == 0 and Cin >= 32 and not (ups and not fold):   # bf16x3 path: dgrad on transposed weights (ops._conv_dgrad)
+    if Cin <= 8 and Cout % 16 == 0 and not (ups and not fold):   # image gradient: dgrad on transposed weights (ops._conv_dgrad)
         wt = torch.empty(Cin * KF * KF * Cout, device=dev)
         lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
         dgrad = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731

@@ -11,7 +11,7 @@ timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; r
 echo "pytest rc=$rc: $(grep -E 'passed|failed' $out/pytest_gpu.log | tail -1)"; grep -E "^FAILED|^ERROR" $out/pytest_gpu.log | head
 [ $rc -ge 124 ] && exit $rc
 timeout -k 10 600 python bench.py > $out/bench_vox64_B16.log 2> $out/bench_vox64_B16.err || exit 1
-echo "bench: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_vox64_B16.log | head -1) $(grep -o '"executed_frac": [0-9.]*' $out/bench_vox64_B16.log) $(grep -o '"bf16x3_path": {"value": [0-9.]*' $out/bench_vox64_B16.log)"
+echo "bench: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_vox64_B16.log | head -1) $(grep -o '"executed_frac": [0-9.]*' $out/bench_vox64_B16.log)"
 Q="--no-cpu-baseline --no-kernel-bench --no-traffic"
 timeout -k 10 300 python bench.py --workload om32 $Q > $out/bench_om32_B32.log 2>&1 || exit 1
 timeout -k 10 300 python bench.py --batch 64 $Q > $out/bench_vox64_B64.log 2>&1 || exit 1
@@ -19,12 +19,12 @@ timeout -k 10 300 python bench.py --reg-param 10 $Q > $out/bench_vox64_B16_r1.lo
 timeout -k 10 300 python bench.py --graph $Q > $out/bench_vox64_B16_graph.log 2>&1 || exit 1
 timeout -k 10 300 python bench.py --workload vox128 $Q > $out/bench_vox128_B2.log 2>&1 || exit 1
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 GIM_FORCE_ALLREDUCE=1 timeout -k 10 300 python bench.py $Q > $out/bench_vox64_B16_rccl1rank.log 2>&1 || exit 1
-timeout -k 10 300 python bench.py $Q --no-bf16x3 > $out/bench_vox64_B16_again.log 2>&1 || exit 1   # box drift check: the default again, after the sustained load above
-for f in om32_B32 vox64_B64 vox64_B16_r1 vox64_B16_graph vox128_B2 vox64_B16_rccl1rank vox64_B16_again; do echo "$f: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$f.log | head -1) $(grep -o '"bf16x3_path": {"value": [0-9.]*' $out/bench_$f.log)"; done
+timeout -k 10 300 python bench.py $Q > $out/bench_vox64_B16_again.log 2>&1 || exit 1   # box drift check: the default again, after the sustained load above
+for f in om32_B32 vox64_B64 vox64_B16_r1 vox64_B16_graph vox128_B2 vox64_B16_rccl1rank vox64_B16_again; do echo "$f: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$f.log | head -1)"; done
 timeout -k 10 300 python tools/conv_shapes_bench.py > $out/conv_shapes_fp32.txt 2>&1 || exit 1
 tail -1 $out/conv_shapes_fp32.txt
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x3 --no-traffic --no-kernel-bench > $out/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --no-kernel-bench > $out/stats.log 2>&1 || exit 1
 # PMC of the dominant conv shapes (one counter set per run), forward / dgrad / wgrad with the geometry the step launches
 mkdir -p $out/pmc
 for probe in "fwd 80 32 64 128 3 0 10 0" "dgrad 80 32 64 128 3 0 10 0" "wgrad 80 32 64 128 3 0 10 0" "fwd 160 64 64 64 3 0 10 1" "dgrad 160 64 64 64 3 0 10 1" "wgrad 160 64 64 64 3 0 10 1" "wgrad 80 8 512 512 3 0 10 1"; do
