@@ -206,6 +206,10 @@ int gim_norm_bwd(const float* dy, const float* x, const float* scale, const floa
 
 /* 2x2 average pool (nn.AvgPool2d(2), models/model_blocks.py:502,509) NHWC; H, W are the INPUT size. */
 int gim_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* The same pool on a tensor that its producer stored ACTIVATED (lrelu(x, in_slope), gim_conv_shape.post_slope / gim_norm_fwd_act /
+ * gim_scale_add_fwd_act): LeakyReLU is inverted on the fly (x = a for a > 0, a / in_slope otherwise), so that the skip path of a
+ * ResBlockDown (models/model_blocks.py:499-503, which reads the RAW block input) can share the activated copy its conv path reads. */
+int gim_avgpool2_fwd_act(const float* x, float* y, int N, int H, int W, int C, float in_slope, void* stream);
 int gim_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* Backward of nearest x2 upsampling: dx[n,h,w,c] = sum of the 2x2 block of dy_up; optional
  * multiplication by leaky_relu'(mask_x) (slope).  H, W are the LOW-resolution size. */
@@ -234,6 +238,8 @@ int gim_softmax_dim1_bwd(const float* dp, const float* p, float* ds, int B, int 
 /* y = gamma * a + x   (models/model_blocks.py:548), gamma a device scalar.  Backward: da = gamma*dy,
  * dgamma = sum(dy * a) (device scalar).  scratch: >= 2048 floats. */
 int gim_scale_add_fwd(const float* a, const float* x, const float* gamma, float* y, int64_t n, void* stream);
+/* y = lrelu(gamma * a + x, post_slope): the SelfAttention output (models/model_blocks.py:548) stored activated for the block behind it. */
+int gim_scale_add_fwd_act(const float* a, const float* x, const float* gamma, float* y, int64_t n, float post_slope, void* stream);
 int gim_scale_add_bwd(const float* dy, const float* a, const float* gamma, float* da, float* dgamma, float* scratch,
                       int64_t n, void* stream);
 

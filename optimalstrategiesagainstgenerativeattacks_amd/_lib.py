@@ -38,6 +38,7 @@ SIGNATURES = {
     "gim_norm_fwd_act": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P],
     "gim_norm_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_avgpool2_fwd": [P, P, c_int, c_int, c_int, c_int, P],
+    "gim_avgpool2_fwd_act": [P, P, c_int, c_int, c_int, c_int, c_float, P],
     "gim_avgpool2_bwd": [P, P, c_int, c_int, c_int, c_int, P],
     "gim_upsample2x_bwd": [P, P, c_float, P, c_int, c_int, c_int, c_int, P],
     "gim_maxpool_lrelu_fwd": [P, P, P, c_int, c_int, c_int, c_float, P],
@@ -47,6 +48,7 @@ SIGNATURES = {
     "gim_softmax_dim1_fwd": [P, P, c_int, c_int, c_int, P],
     "gim_softmax_dim1_bwd": [P, P, P, c_int, c_int, c_int, P],
     "gim_scale_add_fwd": [P, P, P, P, c_int64, P],
+    "gim_scale_add_fwd_act": [P, P, P, P, c_int64, c_float, P],
     "gim_scale_add_bwd": [P, P, P, P, P, P, c_int64, P],
     "gim_tanh_fwd": [P, P, c_int64, P],
     "gim_tanh_bwd": [P, P, P, c_int64, P],

@@ -25,6 +25,22 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restri
         y[i] = 0.25f * (p[0] + p[C] + p[(long long)W * C] + p[(long long)W * C + C]);
     }
 }
+// x stored ACTIVATED (lrelu(x, slope) written by its producer, see gim_conv_shape.post_slope): the pool needs the raw values,
+// and LeakyReLU is invertible - x = a for a > 0, a / slope otherwise (inv = 1 / slope; one rounding more than the raw tensor)
+__global__ __launch_bounds__(256) void avgpool2_fwd_act_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, float inv) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long n_out = (long long)N * Ho * Wo * C;
+    GRID_STRIDE(i, n_out) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const float* p = x + (((long long)n * H + 2 * ho) * W + 2 * wo) * C + c;
+        const float a0 = p[0], a1 = p[C], a2 = p[(long long)W * C], a3 = p[(long long)W * C + C];
+        y[i] = 0.25f * ((a0 > 0.f ? a0 : a0 * inv) + (a1 > 0.f ? a1 : a1 * inv) + (a2 > 0.f ? a2 : a2 * inv) + (a3 > 0.f ? a3 : a3 * inv));
+    }
+}
 __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
     const int Ho = H >> 1, Wo = W >> 1;
     const long long n_in = (long long)N * H * W * C;
@@ -42,6 +58,12 @@ extern "C" int gim_avgpool2_fwd(const float* x, float* y, int N, int H, int W, i
     const long long n = (long long)N * (H / 2) * (W / 2) * C;
     hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
     return gim_check_launch("gim_avgpool2_fwd");
+}
+extern "C" int gim_avgpool2_fwd_act(const float* x, float* y, int N, int H, int W, int C, float in_slope, void* stream) {
+    GIM_CHECK_ARG(x && y && N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && C > 0 && in_slope > 0.f && in_slope <= 1.f, "avgpool2_fwd_act: bad args");
+    const long long n = (long long)N * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(avgpool2_fwd_act_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, 1.0f / in_slope);
+    return gim_check_launch("gim_avgpool2_fwd_act");
 }
 extern "C" int gim_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
     GIM_CHECK_ARG(dy && dx && N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && C > 0, "avgpool2_bwd: bad args");
@@ -265,6 +287,11 @@ __global__ __launch_bounds__(256) void scale_add_fwd_kernel(const float* __restr
     const float g = gamma[0];
     GRID_STRIDE(i, n) y[i] = g * a[i] + x[i];
 }
+__global__ __launch_bounds__(256) void scale_add_fwd_act_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                float* __restrict__ y, long long n, float post_slope) {
+    const float g = gamma[0];
+    GRID_STRIDE(i, n) { const float v = g * a[i] + x[i]; y[i] = fmaxf(v, v * post_slope); }
+}
 __global__ __launch_bounds__(256) void scale_add_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ gamma,
                                                             float* __restrict__ da, float* __restrict__ partial, long long n) {
     __shared__ float red[4];
@@ -289,6 +316,11 @@ extern "C" int gim_scale_add_fwd(const float* a, const float* x, const float* ga
     GIM_CHECK_ARG(a && x && gamma && y && n > 0, "scale_add_fwd: bad args");
     hipLaunchKernelGGL(scale_add_fwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, x, gamma, y, (long long)n);
     return gim_check_launch("gim_scale_add_fwd");
+}
+extern "C" int gim_scale_add_fwd_act(const float* a, const float* x, const float* gamma, float* y, int64_t n, float post_slope, void* stream) {
+    GIM_CHECK_ARG(a && x && gamma && y && n > 0 && post_slope > 0.f && post_slope <= 1.f, "scale_add_fwd_act: bad args");
+    hipLaunchKernelGGL(scale_add_fwd_act_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, x, gamma, y, (long long)n, post_slope);
+    return gim_check_launch("gim_scale_add_fwd_act");
 }
 extern "C" int gim_scale_add_bwd(const float* dy, const float* a, const float* gamma, float* da, float* dgamma, float* scratch,
                                  int64_t n, void* stream) {

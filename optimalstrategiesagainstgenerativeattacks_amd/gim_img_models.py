@@ -96,10 +96,17 @@ class Encoder(nn.Module):
         self.att = mb.SelfAttention(self.channel_sizes[self.att_loc])
 
     def forward(self, x):
+        # Tensors between the blocks are stored ACTIVATED wherever their readers are ResBlockDowns (mb.ResBlockDown.forward_act):
+        # block i's last conv writes lrelu(y) when block i + 1 reads it directly; the attention block reads a raw tensor and
+        # writes an activated one; the last block's output (global max pool) and the image itself stay raw.
+        slope = mb.LRELU if ops.act_storage() else 1.0
+        act = False
         for i in range(self.n_down_blocks):
             if i == self.att_loc:
-                x = self.att(x)
-            x = self.down_blocks[i](x)
+                x = self.att(x, post_slope=slope)
+                act = slope != 1.0
+            want = slope if (i + 1 < self.n_down_blocks and i + 1 != self.att_loc) else 1.0
+            x, act = self.down_blocks[i].forward_act(x, x_act=act, post_slope=want)
         return ops.maxpool_lrelu(x)
 
 
@@ -151,11 +158,17 @@ class Img2ImgDownModule(nn.Module):
         self.att = mb.SelfAttention(self.channel_sizes[self.att_loc])
 
     def forward(self, x):
+        # as in Encoder.forward: the InstanceNorm behind block i writes lrelu(.) when block i + 1 reads it directly
+        slope = mb.LRELU if ops.act_storage() else 1.0
+        act = False
         for i in range(self.n_down_blocks):
             if i == self.att_loc:
-                x = self.att(x)
-            x = self.down_blocks[i](x)
-            x = self.in_layers[i](x)
+                x = self.att(x, post_slope=slope)
+                act = slope != 1.0
+            x, _ = self.down_blocks[i].forward_act(x, x_act=act)
+            want = slope if (i + 1 < self.n_down_blocks and i + 1 != self.att_loc) else 1.0
+            x = self.in_layers[i](x, post_slope=want)
+            act = want != 1.0
         return x
 
 

@@ -140,7 +140,7 @@ class SNConv2d(nn.Module):
             sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
         wf = self.folded() if (pool or (ups and self.kernel_size > 1)) else None
         if post_slope != 1.0:
-            return ops.conv2d_post_act(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope)
+            return ops.conv2d_post_act(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope, x_act)
         return ops.conv2d(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, x_act)
 
     def extra_repr(self):
@@ -271,12 +271,22 @@ class ResBlockDown(nn.Module):
         self.conv_r2 = SNConv2d(out_channel, out_channel, conv_size, padding=padding_size)
 
     def forward(self, x):
-        left = self.conv_l1(ops.avg_pool2(x))
+        return self.forward_act(x)[0]
+
+    def forward_act(self, x, x_act=False, post_slope=1.0):
+        """-> (y, y_act).  x_act: the block input is stored ACTIVATED, lrelu(x) (its producer - the previous block's last conv, an
+        InstanceNorm, the attention's output kernel - wrote it that way): conv_r1, whose K loop would otherwise redo the LeakyReLU
+        for every tap and output tile (10-15 % of that kernel and of its wgrad: every vector instruction of a wave waits for a
+        gap between the other waves' MFMAs, profiles/r03_a_igemm_loop_lab.txt), reads it as it is, and the skip path - which
+        needs the RAW x - inverts the activation inside its pooling kernel (LeakyReLU is a bijection).  post_slope != 1 asks for
+        the block OUTPUT in activated form in turn; y_act says whether it is (a launch that splits K cannot activate)."""
+        left = self.conv_l1(ops.avg_pool2(x, LRELU if x_act else 1.0))
         # conv_r2 is the only reader of conv_r1's output and applies LeakyReLU to it: conv_r1 stores it activated (once per element
-        # in its epilogue) and conv_r2 skips the activation it would otherwise redo for every tap and output tile in its K loop
-        # (-5 ... -10 % of that kernel, profiles/r02_aj_preactivation_cost.txt); launches that split K hand back the raw tensor
-        out, act = self.conv_r1(x, pre_slope=LRELU, post_slope=LRELU)
-        return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True, x_act=act)
+        # in its epilogue); launches that split K hand back the raw tensor
+        out, act = self.conv_r1(x, pre_slope=LRELU, post_slope=LRELU, x_act=x_act)
+        if post_slope != 1.0 and ops.act_storage():
+            return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True, x_act=act, post_slope=post_slope)
+        return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True, x_act=act), False
 
 
 class SelfAttention(nn.Module):
@@ -289,13 +299,14 @@ class SelfAttention(nn.Module):
         self.conv_h = SNConv2d(in_channel, in_channel, 1)
         self.gamma = nn.Parameter(torch.zeros(1))
 
-    def forward(self, x):
+    def forward(self, x, post_slope=1.0):
+        """post_slope != 1: the output gamma * attention + x is written activated (for a ResBlockDown.forward_act behind it)."""
         N, H, W, C = x.shape
         f = self.conv_f(x).view(N, H * W, -1)
         g = self.conv_g(x).view(N, H * W, -1)
         h = self.conv_h(x).view(N, H * W, C)
         out = ops.attn_core(f, g, h).view(N, H, W, C)
-        return ops.scale_add(out, x, self.gamma)
+        return ops.scale_add(out, x, self.gamma, post_slope)
 
 
 class ImgAttConvBlock(nn.Module):

@@ -127,6 +127,23 @@ def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
     return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, 0, 0, 0, 0)
 
 
+# Launch overrides for tools/step_autotune.py (tuning the launch table against the time of the WHOLE overlapped step instead of
+# each kernel alone): {(kind, (N, H, W, Cin, Cout, KH, ups, pool, fold)): (tune_tile, tune_ksplit | tune_wgrad)} with kind
+# "fwd" / "dgrad" / "wgrad".  Empty in the product: the compiled-in table and the heuristics decide.
+_TUNE_OVERRIDE = {}
+
+
+def _tuned(sh, kind, key):
+    ov = _TUNE_OVERRIDE.get((kind, key)) if _TUNE_OVERRIDE else None
+    if ov is not None:
+        sh.tune_tile = ov[0]
+        if kind == "wgrad":
+            sh.tune_wgrad = ov[1]
+        else:
+            sh.tune_ksplit = ov[1]
+    return sh
+
+
 # Outputs of split-K launches.  A layer whose output tiles do not fill the chip is sliced along K over the grid and its slices
 # are combined with float atomics into a ZEROED output: ~250 such launches per training step, each with its own memset in front
 # (a 7 us fill kernel plus a kernel boundary).  Instead those outputs are carved out of pages that ONE torch.zeros call clears
@@ -424,6 +441,7 @@ class ConvFn(Function):
         sh = _shape(N, H, W, Cin, Cout, KH, ups, 1.0 if x_act else pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
         Ho, Wo = (H >> 1, W >> 1) if pool else (H, W)
         key = (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold)
+        _tuned(sh, "fwd", key)
         # post_slope != 1: store lrelu(y) for a consumer that is the ONLY reader of y and runs with x_act.  conv2d_post_act has
         # resolved it (1.0 when the launch splits K: the slices combine by addition); a split-K launch refuses it here
         if post_slope != 1.0:
@@ -465,14 +483,19 @@ class ConvFn(Function):
         dev = dy.device
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, ctx.cfg, st, w)
+            sh_d = sh
+            if _TUNE_OVERRIDE:
+                sh_d = _tuned(_shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0), "dgrad",
+                              (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold))
+            dx = _conv_dgrad(lib, dy, x, wp, wf, sigma, sh_d, ctx.cfg, st, w)
         want_w = ctx.needs_input_grad[1]
         want_b = has_bias and ctx.needs_input_grad[2]
         Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
         if want_w:
             sh_w = sh
-            if ctx.x_act:   # the stored x is already lrelu(x): no activation on the wgrad operand
-                sh_w = _shape(N, H, W, Cin, Cout, KH, ups, 1.0, 1 if pool else 0, fold, 1 if res_ups else 0)
+            if ctx.x_act or _TUNE_OVERRIDE:   # x_act: the stored x is already lrelu(x): no activation on the wgrad operand
+                sh_w = _tuned(_shape(N, H, W, Cin, Cout, KH, ups, 1.0 if ctx.x_act else pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0),
+                              "wgrad", (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold))
             dw, db = _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh_w, ctx.cfg, want_b, st)
         elif want_b:
             db = torch.empty(Cout, device=dev, dtype=torch.float32)
@@ -677,7 +700,7 @@ def conv2d(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre
 
 
 def conv2d_post_act(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, wf=None,
-                    guard=None, post_slope=1.0):
+                    guard=None, post_slope=1.0, x_act=False):
     """conv2d whose output may be stored ACTIVATED, y_stored = lrelu(y, post_slope), for a consumer conv that is the only reader
     of y and is then called with x_act=True (it skips its per-tap LeakyReLU in forward and wgrad; its dgrad masks by the sign,
     which activation does not change, and hands back the gradient w.r.t. the RAW y - so this conv's backward is unchanged).
@@ -690,9 +713,10 @@ def conv2d_post_act(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, u
         Cout, KH = w.shape[0], (w.shape[2] if w.dim() == 4 else 1)
         H, W = Hs << ups, Ws << ups
         fold = 1 if (pool or (ups and KH > 1)) else 0
-        sh = _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0)
-        act = not _splits_k(sh, 0, (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold))
-    y = ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope if act else 1.0, False)
+        key = (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold)
+        sh = _tuned(_shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0), "fwd", key)
+        act = not _splits_k(sh, 0, key)
+    y = ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope if act else 1.0, x_act)
     return y, act
 
 
@@ -782,19 +806,26 @@ def act_storage():
 # pooling / pointwise
 # --------------------------------------------------------------------------------------------
 class AvgPool2Fn(Function):
+    """2x2 average pool.  in_slope != 1: x is stored ACTIVATED (lrelu(x, in_slope) written by its producer for the conv that reads
+    it next to this pool); the kernel inverts the activation on the fly.  The gradient handed back is w.r.t. the RAW x - what
+    every consumer of an activated tensor returns (ConvFn with x_act) - and does not depend on x: the backward is unchanged."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, in_slope=1.0):
         lib = _lib.load()
         x = _req(x, "x")
         N, H, W, C = x.shape
         y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
-        check(lib.gim_avgpool2_fwd(_p(x), _p(y), N, H, W, C, _stream()), "avgpool2_fwd")
+        if in_slope != 1.0:
+            check(lib.gim_avgpool2_fwd_act(_p(x), _p(y), N, H, W, C, in_slope, _stream()), "avgpool2_fwd_act")
+        else:
+            check(lib.gim_avgpool2_fwd(_p(x), _p(y), N, H, W, C, _stream()), "avgpool2_fwd")
         ctx.cfg = (N, H, W, C)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        return AvgPool2BwdFn.apply(dy, ctx.cfg)
+        return AvgPool2BwdFn.apply(dy, ctx.cfg), None
 
 
 class AvgPool2BwdFn(Function):
@@ -882,14 +913,19 @@ class TanhFn(Function):
 
 
 class ScaleAddFn(Function):
-    """y = gamma * a + x with gamma a 1-element parameter (SelfAttention output)."""
+    """y = gamma * a + x with gamma a 1-element parameter (SelfAttention output).  post_slope != 1: y is stored activated,
+    lrelu(y, post_slope), for consumers that take activated storage (ConvFn x_act, AvgPool2Fn in_slope); they hand back the
+    gradient w.r.t. the raw y, and this backward never reads y."""
 
     @staticmethod
-    def forward(ctx, a, x, gamma):
+    def forward(ctx, a, x, gamma, post_slope=1.0):
         lib = _lib.load()
         a, x = _req(a, "a"), _req(x, "x")
         y = torch.empty_like(x)
-        check(lib.gim_scale_add_fwd(_p(a), _p(x), _p(gamma), _p(y), x.numel(), _stream()), "scale_add_fwd")
+        if post_slope != 1.0:
+            check(lib.gim_scale_add_fwd_act(_p(a), _p(x), _p(gamma), _p(y), x.numel(), post_slope, _stream()), "scale_add_fwd_act")
+        else:
+            check(lib.gim_scale_add_fwd(_p(a), _p(x), _p(gamma), _p(y), x.numel(), _stream()), "scale_add_fwd")
         ctx.save_for_backward(a, gamma)
         return y
 
@@ -899,12 +935,12 @@ class ScaleAddFn(Function):
         a, gamma = ctx.saved_tensors
         dy = _req(dy, "dy")
         if _second_order():
-            return (MulScalarFn.apply(dy, gamma) if ctx.needs_input_grad[0] else None), dy, None
+            return (MulScalarFn.apply(dy, gamma) if ctx.needs_input_grad[0] else None), dy, None, None
         da = torch.empty_like(a)
         dg = torch.empty(1, device=dy.device, dtype=torch.float32)
         scratch = torch.empty(2048, device=dy.device, dtype=torch.float32)
         check(lib.gim_scale_add_bwd(_p(dy), _p(a), _p(gamma), _p(da), _p(dg), _p(scratch), a.numel(), _stream()), "scale_add_bwd")
-        return da, dy, dg.view_as(gamma)
+        return da, dy, dg.view_as(gamma), None
 
 
 class MulScalarFn(Function):

@@ -422,7 +422,10 @@ def test_trainer_protocol_vs_reference_golden(tag):
                 mine = opt.state[named[name]]["exp_avg_sq"].detach().double().reshape(-1)[::int(stride)].cpu().numpy()
                 ref = g[k_]
                 l2 = float(np.linalg.norm(mine - ref) / max(np.linalg.norm(ref), 1e-30))
-                assert l2 < 3e-3, ("Adam second moment sample", nm, name, l2)
+                # v = 0.01 g^2 summed over the iterations: twice the gradient's relative error.  The gradient bounds of _check_nets
+                # (3e-3, EnvDecoder 6e-3: its first blocks normalise 1x1 - 4x4 maps) give 6e-3 / 1.2e-2; measured
+                # 3.4e-3 on env_decoder.up_blocks.0.conv_r2 (run to run: the order of the float atomics), <= 1e-3 elsewhere
+                assert l2 < (1.2e-2 if name.startswith("env_decoder.") else 6e-3), ("Adam second moment sample", nm, name, l2)
                 n_checked += 1
     assert n_checked > 600, n_checked
 
