@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, lab_lds_bytes(BM, BN, KB, VAR) <= 40960 ? 4 : 
 
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto now = [&]() -> unsigned long long { return STAMP ? __builtin_amdgcn_s_memtime() : 0ull; };
+    const unsigned long long c_begin = now(), r_begin = STAMP ? __builtin_amdgcn_s_memrealtime() : 0ull;   // shader cycles / 100 MHz ticks
 
     const int nk = K / KB;
     if constexpr (DMA) {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256, lab_lds_bytes(BM, BN, KB, VAR) <= 40960 ? 4 : 
         __syncthreads();
         if constexpr (STAMP) {
             const unsigned long long t6 = now();
-            st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3; st[4] += t5 - t4; st[5] += t6 - t5; st[6] += 1;
+            st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t5 - t3; st[5] += t6 - t5; st[6] += 1;
         }
     };
     int ks = 0;
@@ -240,6 +241,9 @@ __global__ __launch_bounds__(256, lab_lds_bytes(BM, BN, KB, VAR) <= 40960 ? 4 : 
         }
     if constexpr (STAMP) {
         st[7] = now() - te0;
+        // in-kernel shader clock of this wave's lifetime: cycles per 100 MHz tick, x1000 (slot 5 is re-used: barrier time moves out)
+        const unsigned long long dc = now() - c_begin, dr = __builtin_amdgcn_s_memrealtime() - r_begin;
+        st[4] = dr ? dc * 1000ull / dr : 0ull;   // (slot 4 = lds-write time is folded into slot 3 for this probe)
         if (lane == 0) {
             unsigned long long* o = p.stamps + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 8;
             for (int i = 0; i < 8; ++i) o[i] = st[i];
@@ -303,12 +307,13 @@ static Result run(LabP p, const char* name, const std::vector<double>& ref, int 
         double tot[8] = {0};
         for (long long w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) tot[i] += (double)hs[w * 8 + i];
         for (int i = 0; i < 6; ++i) res.ph[i] = tot[i] / tot[6];
+        res.ph[4] = tot[4] / nw / 10.0;   // MHz (mean over waves): cycles per 10 ns tick x 100
         res.ph[7] = tot[7] / nw;
         CK(hipFree(stamps));
     }
     if (print) {
         printf("%-44s %4dx%-3d KB%-2d  %8.4f ms %7.1f TF  err %.1e", name, BM, BN, KB, res.ms, res.tf, res.err);
-        if (STAMP) printf("  cycles/K-step/wave: issue-loads %.0f | lds-read %.0f | mfma %.0f | vmcnt %.0f | lds-write %.0f | barrier %.0f ; epilogue %.0f",
+        if (STAMP) printf("  cycles/K-step/wave: issue-loads %.0f | lds-read %.0f | mfma %.0f | vmcnt %.0f | in-kernel clock %.0f MHz | barrier %.0f ; epilogue %.0f",
                           res.ph[0], res.ph[1], res.ph[2], res.ph[3], res.ph[4], res.ph[5], res.ph[7]);
         printf("\n");
     }
@@ -351,29 +356,13 @@ int main(int argc, char** argv) {
             std::vector<double> ref((size_t)ref_rows * s.N);
             CK(hipMemcpy(ref.data(), dref, ref.size() * 8, hipMemcpyDeviceToHost));
             printf("-- pre-activation slope %.1f%s\n", p.slope, p.oob_test ? ", zero-padding lanes (BUF_OOB) on tap 1" : "");
-            for (int round = 0; round < 2; ++round) {   // two interleaved rounds: the second shows the run-to-run spread
-                for (int pr = 0; pr < 4; ++pr) {
-                    if (pr == 1) continue;
-                    p.prio = pr;
-                    char nm[64];
-                    snprintf(nm, sizeof nm, "staged, prio mode %d", pr);
-                    run<64, 64, 1, 1, 32, 0, false>(p, nm, ref, ref_rows);
-                    if (s.N >= 128) run<64, 128, 1, 2, 16, 0, false>(p, nm, ref, ref_rows);
-                    run<128, 64, 2, 1, 16, 0, false>(p, nm, ref, ref_rows);
-                    snprintf(nm, sizeof nm, "LDS-DMA, prio mode %d", pr);
-                    run<64, 64, 1, 1, 32, 1, false>(p, nm, ref, ref_rows);
-                    if (s.N >= 128) run<64, 128, 1, 2, 32, 1, false>(p, nm, ref, ref_rows);
-                }
+            for (int round = 0; round < 3; ++round) {
+                run<64, 64, 1, 1, 32, 0, false>(p, "staged", ref, ref_rows);
+                if (s.N >= 128) run<64, 128, 1, 2, 16, 0, false>(p, "staged", ref, ref_rows);
+                run<128, 64, 2, 1, 16, 0, false>(p, "staged", ref, ref_rows);
+                run<64, 64, 1, 1, 32, 0, true>(p, "staged, STAMPED", ref, ref_rows);
+                if (s.N >= 128) run<64, 128, 1, 2, 16, 0, true>(p, "staged, STAMPED", ref, ref_rows);
             }
-            for (int pr = 0; pr < 4; ++pr) {
-                if (pr == 1) continue;
-                p.prio = pr;
-                char nm[64];
-                snprintf(nm, sizeof nm, "staged, STAMPED, prio mode %d", pr);
-                run<64, 64, 1, 1, 32, 0, true>(p, nm, ref, ref_rows);
-                if (s.N >= 128) run<64, 128, 1, 2, 16, 0, true>(p, nm, ref, ref_rows);
-            }
-            p.prio = 0;
         }
         CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy)); CK(hipFree(dref));
     }
