@@ -71,6 +71,14 @@ typedef struct {
 
 /* F[co][a][b][ci] = sum_{dh,dw in {0,1}} w[co][a-dh][b-dw][ci], a, b in [0, KH]  (out-of-range taps are zero). */
 int gim_conv2d_fold_weights(const float* w, float* f, int Cout, int Cin, int KH, void* stream);
+/* The folds of MANY convolutions in one launch (a model folds ~20 weight tensors once per optimizer step): `jobs` and `tab` in
+ * device memory, tab = n_blocks x {job, chunk of 65536 folded elements}. */
+typedef struct {
+    const float* w;
+    float* f;
+    int32_t Cout, Cin, KH, reserved;
+} gim_fold_job;
+int gim_conv2d_fold_weights_batched(const gim_fold_job* jobs, const int32_t* tab, int n_blocks, void* stream);
 
 /* y = conv(x~, w) / sigma + bias + residual.
  * Replaces F.conv2d behind nn.Conv2d + spectral_norm (models/model_blocks.py:492-495,522-526,744-750,
@@ -210,6 +218,11 @@ int gim_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void*
  * gim_scale_add_fwd_act): LeakyReLU is inverted on the fly (x = a for a > 0, a / in_slope otherwise), so that the skip path of a
  * ResBlockDown (models/model_blocks.py:499-503, which reads the RAW block input) can share the activated copy its conv path reads. */
 int gim_avgpool2_fwd_act(const float* x, float* y, int N, int H, int W, int C, float in_slope, void* stream);
+/* Gradient fan-in of a tensor with several consumers in ONE pass (autograd's AccumulateGrad / input-buffer additions, one launch
+ * per extra consumer): out = a + b (+ c) (+ d) (c, d may be NULL);  and the ResBlockDown form (models/model_blocks.py:499-510:
+ * x feeds the conv path and, through AvgPool2d, the skip path): out = g + avgpool2_bwd(dy_pooled), g and out [N][H][W][C]. */
+int gim_add_n(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n, void* stream);
+int gim_add_avgpool2_bwd(const float* g, const float* dy_pooled, float* out, int N, int H, int W, int C, void* stream);
 int gim_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* Backward of nearest x2 upsampling: dx[n,h,w,c] = sum of the 2x2 block of dy_up; optional
  * multiplication by leaky_relu'(mask_x) (slope).  H, W are the LOW-resolution size. */
@@ -230,6 +243,24 @@ int gim_attn_prob_fwd(const float* f, const float* g, float* P, int batch, int T
  * models/model_blocks.py:539-544 and their autograd).  Element strides; C is row-major [b][M][N]. */
 int gim_bgemm(const float* A, const float* B, float* C, int batch, int M, int N, int K,
               int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, void* stream);
+
+/* Grouped form: n independent small products C = A * B (+ bias), each with its own operands, element strides and output, in ONE
+ * launch - the 36 style projections nn.Linear(style_dim, C) of the generator's AdaIN blocks on one shared style matrix
+ * (models/model_blocks.py:786-789,829-832 and their autograd: forward, input gradient, weight gradient = three launches instead
+ * of 108).  `jobs` and `tiles` live in DEVICE memory; tiles = n_tiles x {job, row tile, column tile} of 64 x 64 outputs.
+ *   flags bit 0: C += product (one writer per element);  bit 1: all jobs add into one pre-zeroed C with float atomics.
+ * gim_colsum_grouped: C[j] (+)= sum_i A[i * sAi + j * sAk] per job (bias gradients; tiles = {job, 0, block of 64 columns}). */
+typedef struct {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;           /* per output column, or NULL */
+    int32_t M, N, K, ldc;        /* C is row-major with leading dimension ldc */
+    int64_t sAi, sAk, sBk, sBj;  /* element strides of A(i, k) and B(k, j) */
+    int32_t flags, reserved;
+} gim_gemm_job;
+int gim_bgemm_grouped(const gim_gemm_job* jobs, const int32_t* tiles, int n_tiles, void* stream);
+int gim_colsum_grouped(const gim_gemm_job* jobs, const int32_t* tiles, int n_tiles, void* stream);
 
 /* Softmax over dim -2 of [B][R][Ccols] (nn.Softmax(-2), models/model_blocks.py:528,540): columns sum to 1. */
 int gim_softmax_dim1_fwd(const float* s, float* p, int B, int R, int Ccols, void* stream);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "gim_conv2d_wgrad": [P, P, P, P, c_int, SP, P],
     "gim_wgrad_finish": [P, P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P],
     "gim_conv2d_fold_weights": [P, P, c_int, c_int, c_int, P],
+    "gim_conv2d_fold_weights_batched": [P, P, c_int, P],
     "gim_spectral_sigma": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_spectral_sigma_batched": [P, c_int, P, c_int, P, c_int, P, c_int, P],
     "gim_colsum": [P, P, P, c_int64, c_int, P],
@@ -39,6 +40,8 @@ SIGNATURES = {
     "gim_norm_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_avgpool2_fwd": [P, P, c_int, c_int, c_int, c_int, P],
     "gim_avgpool2_fwd_act": [P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "gim_add_n": [P, P, P, P, P, c_int64, P],
+    "gim_add_avgpool2_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_avgpool2_bwd": [P, P, c_int, c_int, c_int, c_int, P],
     "gim_upsample2x_bwd": [P, P, c_float, P, c_int, c_int, c_int, c_int, P],
     "gim_maxpool_lrelu_fwd": [P, P, P, c_int, c_int, c_int, c_float, P],
@@ -47,6 +50,8 @@ SIGNATURES = {
     "gim_attn_prob_fwd": [P, P, P, c_int, c_int, c_int, P],
     "gim_softmax_dim1_fwd": [P, P, c_int, c_int, c_int, P],
     "gim_softmax_dim1_bwd": [P, P, P, c_int, c_int, c_int, P],
+    "gim_bgemm_grouped": [P, P, c_int, P],
+    "gim_colsum_grouped": [P, P, c_int, P],
     "gim_scale_add_fwd": [P, P, P, P, c_int64, P],
     "gim_scale_add_fwd_act": [P, P, P, P, c_int64, c_float, P],
     "gim_scale_add_bwd": [P, P, P, P, P, P, c_int64, P],

@@ -982,6 +982,36 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const float* __restri
     }
 }
 
+// all folds of a model in one launch: block b works on chunk tab[2b+1] (of 65536 elements) of job tab[2b]
+__global__ __launch_bounds__(256) void fold_weights_batched_kernel(const gim_fold_job* __restrict__ jobs, const int* __restrict__ tab) {
+    const gim_fold_job jb = jobs[tab[2 * blockIdx.x]];
+    const int K = jb.KH, KF = K + 1, Cin = jb.Cin;
+    const long long n = (long long)jb.Cout * KF * KF * Cin;
+    const long long lo = (long long)tab[2 * blockIdx.x + 1] * 65536, hi = lo + 65536 < n ? lo + 65536 : n;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const int ci = (int)(i % Cin);
+        long long rr = i / Cin;
+        const int b = (int)(rr % KF); rr /= KF;
+        const int a = (int)(rr % KF);
+        const int co = (int)(rr / KF);
+        float s = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const int kh = a - dh, kw = b - dw;
+                if (kh >= 0 && kh < K && kw >= 0 && kw < K) s += jb.w[(((long long)co * K + kh) * K + kw) * Cin + ci];
+            }
+        jb.f[i] = s;
+    }
+}
+
+extern "C" int gim_conv2d_fold_weights_batched(const gim_fold_job* jobs, const int32_t* tab, int n_blocks, void* stream) {
+    GIM_CHECK_ARG(jobs && tab && n_blocks > 0, "fold_weights_batched: bad args");
+    hipLaunchKernelGGL(fold_weights_batched_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, jobs, (const int*)tab);
+    return gim_check_launch("gim_conv2d_fold_weights_batched");
+}
+
 extern "C" int gim_conv2d_fold_weights(const float* w, float* f, int Cout, int Cin, int KH, void* stream) {
     GIM_CHECK_ARG(w && f && Cout > 0 && Cin > 0 && KH > 0 && (KH & 1), "fold_weights: bad args");
     const long long n = (long long)Cout * (KH + 1) * (KH + 1) * Cin;

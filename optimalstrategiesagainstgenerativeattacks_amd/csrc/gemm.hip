@@ -89,6 +89,121 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgP p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Grouped form: many small independent products in ONE launch, each with its own operands, strides and output (a job table on
+// the device, one workgroup per (job, 64 x 64 tile)).  The generator's 36 style projections (models/model_blocks.py:776-865:
+// lin1_mean / lin1_std / lin2_mean / lin2_std of every AdaResBlock2 / AdaResBlockUp2, nn.Linear(512, C) on ONE shared style
+// matrix [B * n, 512]) are 36 forward, 36 input-gradient and 36 weight-gradient products of 5-7 us each, launch-bound; as
+// three grouped launches they are what they compute: ~1 GFLOP.  flags bit 0: C += product (single writer per element: the
+// weight gradients add into the optimizer's bucket); bit 1: combine with float atomics (all jobs add into one C: the gradient
+// w.r.t. the shared input, pre-zeroed by the caller).  bias: added per output column (forward).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bgemm_grouped_kernel(const gim_gemm_job* __restrict__ jobs, const int* __restrict__ tiles) {
+    __shared__ float As[2][GK * GLD];
+    __shared__ float Bs[2][GK * GLD];
+    const int t = threadIdx.x;
+    const int job = tiles[3 * blockIdx.x], i0 = tiles[3 * blockIdx.x + 1] * GB, j0 = tiles[3 * blockIdx.x + 2] * GB;
+    const gim_gemm_job p = jobs[job];
+    const float* A = p.A;
+    const float* B = p.B;
+    const bool a_kfast = (p.sAk == 1);
+    const bool b_jfast = (p.sBj == 1);
+    float ra[4], rb[4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = t + 256 * e;
+            int i, k;
+            if (a_kfast) { k = idx & 15; i = idx >> 4; } else { i = idx & 63; k = idx >> 6; }
+            const bool v = (i0 + i) < p.M && (k0 + k) < p.K;
+            ra[e] = v ? A[(long long)(i0 + i) * p.sAi + (long long)(k0 + k) * p.sAk] : 0.f;
+            int j, kb;
+            if (b_jfast) { j = idx & 63; kb = idx >> 6; } else { kb = idx & 15; j = idx >> 4; }
+            const bool vb = (j0 + j) < p.N && (k0 + kb) < p.K;
+            rb[e] = vb ? B[(long long)(k0 + kb) * p.sBk + (long long)(j0 + j) * p.sBj] : 0.f;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = t + 256 * e;
+            int i, k;
+            if (a_kfast) { k = idx & 15; i = idx >> 4; } else { i = idx & 63; k = idx >> 6; }
+            As[buf][k * GLD + i] = ra[e];
+            int j, kb;
+            if (b_jfast) { j = idx & 63; kb = idx >> 6; } else { kb = idx & 15; j = idx >> 4; }
+            Bs[buf][kb * GLD + j] = rb[e];
+        }
+    };
+    const int lane = t & 63, r = lane & 31, h = lane >> 5, wv = t >> 6;
+    const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int nk = (p.K + GK - 1) / GK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_tiles((ks + 1) * GK);
+#pragma unroll
+        for (int kp = 0; kp < GK / 2; ++kp) {
+            const float a = As[buf][(2 * kp + h) * GLD + wm0 + r];
+            const float b = Bs[buf][(2 * kp + h) * GLD + wn0 + r];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (ks + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    const int j = j0 + wn0 + r;
+    if (j < p.N) {
+        const float bv = p.bias ? p.bias[j] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (i < p.M) {
+                float* c = p.C + (long long)i * p.ldc + j;
+                const float v = acc[e] + bv;
+                if (p.flags & 2) atomicAdd(c, v);
+                else if (p.flags & 1) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+// column sums of many small matrices in one launch: out[j] (+)= sum_i A[i][j]  (the bias gradients of the grouped linears);
+// one workgroup per (job, block of 64 columns); the job's B / C / bias fields are unused, out = C, flags bit 0 = accumulate
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(const gim_gemm_job* __restrict__ jobs, const int* __restrict__ tiles) {
+    __shared__ float red[4][64];
+    const int job = tiles[3 * blockIdx.x], j0 = tiles[3 * blockIdx.x + 2] * 64;
+    const gim_gemm_job p = jobs[job];
+    const int j = j0 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float s = 0.f;
+    if (j < p.N)
+        for (int i = part; i < p.M; i += 4) s += p.A[(long long)i * p.sAi + (long long)j * p.sAk];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && j < p.N) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (p.flags & 1) p.C[j] += v;
+        else p.C[j] = v;
+    }
+}
+
+extern "C" int gim_bgemm_grouped(const gim_gemm_job* jobs, const int32_t* tiles, int n_tiles, void* stream) {
+    GIM_CHECK_ARG(jobs && tiles && n_tiles > 0, "bgemm_grouped: bad args");
+    hipLaunchKernelGGL(bgemm_grouped_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, jobs, (const int*)tiles);
+    return gim_check_launch("gim_bgemm_grouped");
+}
+
+extern "C" int gim_colsum_grouped(const gim_gemm_job* jobs, const int32_t* tiles, int n_tiles, void* stream) {
+    GIM_CHECK_ARG(jobs && tiles && n_tiles > 0, "colsum_grouped: bad args");
+    hipLaunchKernelGGL(colsum_grouped_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, jobs, (const int*)tiles);
+    return gim_check_launch("gim_colsum_grouped");
+}
+
 // Vector form of the same product for operands whose unit-stride extent is a multiple of 4 and 16-byte aligned (every
 // SelfAttention product of the benchmark shapes): one 16-byte global load per thread, operand and 16 K values instead of four
 // scalar loads with 64-bit address arithmetic each, K step 32 (16 MFMAs per wave between barriers instead of 8), LDS rows of 68

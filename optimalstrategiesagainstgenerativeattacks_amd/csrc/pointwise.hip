@@ -65,6 +65,42 @@ extern "C" int gim_avgpool2_fwd_act(const float* x, float* y, int N, int H, int 
     hipLaunchKernelGGL(avgpool2_fwd_act_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, 1.0f / in_slope);
     return gim_check_launch("gim_avgpool2_fwd_act");
 }
+// Gradient fan-in of a tensor with several consumers, in one pass (autograd would add the incoming gradients pairwise, one
+// launch and one full read-modify-write each): out = a + b (+ c) (+ d);  and the ResBlockDown form, where the second consumer
+// is the 2x2 average pool of the skip path: out = g + avgpool2_bwd(dy_pooled) without materialising the un-pooled gradient.
+__global__ __launch_bounds__(256) void add_n_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                    const float* __restrict__ d, float* __restrict__ out, long long n) {
+    GRID_STRIDE(i, n) {
+        float v = a[i] + b[i];
+        if (c) v += c[i];
+        if (d) v += d[i];
+        out[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void add_avgpool2_bwd_kernel(const float* __restrict__ g, const float* __restrict__ dy, float* __restrict__ out,
+                                                               int N, int H, int W, int C) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long n_in = (long long)N * H * W * C;
+    GRID_STRIDE(i, n_in) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        out[i] = g[i] + 0.25f * dy[(((long long)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c];
+    }
+}
+extern "C" int gim_add_n(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n, void* stream) {
+    GIM_CHECK_ARG(a && b && out && n > 0 && (c || !d), "add_n: bad args");
+    hipLaunchKernelGGL(add_n_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, c, d, out, (long long)n);
+    return gim_check_launch("gim_add_n");
+}
+extern "C" int gim_add_avgpool2_bwd(const float* g, const float* dy, float* out, int N, int H, int W, int C, void* stream) {
+    GIM_CHECK_ARG(g && dy && out && N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && C > 0, "add_avgpool2_bwd: bad args");
+    const long long n = (long long)N * H * W * C;
+    hipLaunchKernelGGL(add_avgpool2_bwd_kernel, dim3(pw_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, dy, out, N, H, W, C);
+    return gim_check_launch("gim_add_avgpool2_bwd");
+}
 extern "C" int gim_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
     GIM_CHECK_ARG(dy && dx && N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && C > 0, "avgpool2_bwd: bad args");
     const long long n = (long long)N * H * W * C;

@@ -240,8 +240,20 @@ class AdaInImage2Image(nn.Module):
             side = _side_streams(x.device)[0]
             ops.stream_wait(side, cur)
             with torch.cuda.stream(side):
-                svs_res = [b.style_vectors(style) for b in self.adain_res_block.res_blocks]
-                svs_up = [b.style_vectors(style) for b in self.adain_up_block.up_blocks]
+                if torch.cuda.is_current_stream_capturing():
+                    # (the grouped launch addresses its outputs and gradients through job tables built per allocation: under a
+                    #  hipGraph capture the layers run one by one)
+                    svs_res = [b.style_vectors(style) for b in self.adain_res_block.res_blocks]
+                    svs_up = [b.style_vectors(style) for b in self.adain_up_block.up_blocks]
+                else:
+                    # all 36 style projections (4 per AdaIN block) in ONE grouped launch (ops.GroupedLinearFn)
+                    blocks = list(self.adain_res_block.res_blocks) + list(self.adain_up_block.up_blocks)
+                    lins = [l_ for b in blocks for l_ in (b.lin1_mean, b.lin1_std, b.lin2_mean, b.lin2_std)]
+                    shp = style.shape
+                    ys = ops.grouped_linear(style.reshape(-1, shp[-1]), [(l_.weight, l_.bias) for l_ in lins])
+                    ys = [y.view(*shp[:-1], y.shape[-1]) for y in ys]
+                    svs = [tuple(ys[4 * i:4 * i + 4]) for i in range(len(blocks))]
+                    svs_res, svs_up = svs[:len(self.adain_res_block.res_blocks)], svs[len(self.adain_res_block.res_blocks):]
             style.record_stream(side)
         x = self.down_block(x)
         if svs_res is not None:

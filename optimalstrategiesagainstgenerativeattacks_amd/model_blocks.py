@@ -111,12 +111,14 @@ class SNConv2d(nn.Module):
 
         self._sn_queue = collections.deque()  # (sigma, u, v) triples precomputed by an SNPlan round
         self._fold_cache = (None, None, None, None, False)   # ((storage, version, optimizer epoch), folded weights F, ready event, stream, recorded in a capture)
+        self._wants_fold = False    # set by the first folded() call: SNPlan.run then folds this conv together with the others
 
     def folded(self):
         """The (k+1)^2-tap folded weights for the pool / sub-pixel forms, recomputed only when weight_orig changed
         (autograd version counter for torch-side writes, optim.weights_epoch(w) for the fused Adam kernel)."""
         from . import optim
         w = self.weight_orig
+        self._wants_fold = True
         key = (w.data_ptr(), w._version, optim.weights_epoch(w))
         raw = ops._stream()   # raw handle: building a torch Stream object per call costs microseconds of host time
         if self._fold_cache[0] != key:
@@ -230,6 +232,47 @@ class SNPlan:
                                                       torch.cuda.current_stream().cuda_stream), "spectral_sigma_batched")
             for c, (o_s, o_u, Cout, o_v, K) in zip(self.convs, self._views):
                 c._sn_queue.append((out[o_s:o_s + 1], out[o_u:o_u + Cout], out[o_v:o_v + K], (self, gen)))
+        self._fold_stale()
+
+    def _fold_stale(self):
+        """The folded weights (pool / sub-pixel forms) of every conv of the plan whose weights changed since its last fold, in ONE
+        launch (each conv would otherwise fold itself at its first use: ~30 launches of ~10 us per training step, on the
+        forward's critical path).  Results go where SNConv2d.folded() keeps them."""
+        from . import optim
+        todo = []
+        for c in self.convs:
+            if c._wants_fold:
+                w = c.weight_orig
+                key = (w.data_ptr(), w._version, optim.weights_epoch(w))
+                if c._fold_cache[0] != key:
+                    todo.append((c, key))
+        if len(todo) < 2:
+            return     # a single stale conv folds itself at its call
+        dev = todo[0][0].weight_orig.device
+        sig = tuple(c.weight_orig.data_ptr() for c, _ in todo)
+        ent = getattr(self, "_fold_tab", {}).get(sig)
+        if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            jobs = np.zeros(len(todo), dtype=np.dtype([("w", "<u8"), ("f", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("KH", "<i4"), ("r", "<i4")]))
+            bufs, tab = [], []
+            for j, (c, _) in enumerate(todo):
+                KF = c.kernel_size + 1
+                n = c.out_channels * KF * KF * c.in_channels
+                f = torch.empty(n, device=dev, dtype=torch.float32)
+                bufs.append(f)
+                jobs[j] = (c.weight_orig.data_ptr(), f.data_ptr(), c.out_channels, c.in_channels, c.kernel_size, 0)
+                tab += [(j, ch) for ch in range((n + 65535) // 65536)]
+            ent = (torch.from_numpy(jobs.view(np.uint8).copy()).to(dev), torch.tensor(tab, dtype=torch.int32).to(dev), len(tab), bufs)
+            if not hasattr(self, "_fold_tab"):
+                self._fold_tab = {}
+            self._fold_tab[sig] = ent
+        dj, dt, nb, bufs = ent
+        _lib.check(_lib.load().gim_conv2d_fold_weights_batched(dj.data_ptr(), dt.data_ptr(), nb, ops._stream()), "fold_weights_batched")
+        ev = torch.cuda.current_stream().record_event()
+        raw, cap = ops._stream(), torch.cuda.is_current_stream_capturing()
+        for (c, key), f in zip(todo, bufs):
+            c._fold_cache = (key, f, ev, raw, cap)
 
 
 def sn_convs(*modules):
@@ -280,7 +323,8 @@ class ResBlockDown(nn.Module):
         gap between the other waves' MFMAs, profiles/r03_a_igemm_loop_lab.txt), reads it as it is, and the skip path - which
         needs the RAW x - inverts the activation inside its pooling kernel (LeakyReLU is a bijection).  post_slope != 1 asks for
         the block OUTPUT in activated form in turn; y_act says whether it is (a launch that splits K cannot activate)."""
-        left = self.conv_l1(ops.avg_pool2(x, LRELU if x_act else 1.0))
+        x, pooled = ops.fork_pool(x, LRELU if x_act else 1.0)   # the two consumers of x; their gradients meet in one kernel
+        left = self.conv_l1(pooled)
         # conv_r2 is the only reader of conv_r1's output and applies LeakyReLU to it: conv_r1 stores it activated (once per element
         # in its epilogue); launches that split K hand back the raw tensor
         out, act = self.conv_r1(x, pre_slope=LRELU, post_slope=LRELU, x_act=x_act)
@@ -302,11 +346,12 @@ class SelfAttention(nn.Module):
     def forward(self, x, post_slope=1.0):
         """post_slope != 1: the output gamma * attention + x is written activated (for a ResBlockDown.forward_act behind it)."""
         N, H, W, C = x.shape
-        f = self.conv_f(x).view(N, H * W, -1)
-        g = self.conv_g(x).view(N, H * W, -1)
-        h = self.conv_h(x).view(N, H * W, C)
+        xf, xg, xh, xr = ops.fork(x, 4)     # four consumers of x: their gradients are added by one kernel, not three
+        f = self.conv_f(xf).view(N, H * W, -1)
+        g = self.conv_g(xg).view(N, H * W, -1)
+        h = self.conv_h(xh).view(N, H * W, C)
         out = ops.attn_core(f, g, h).view(N, H, W, C)
-        return ops.scale_add(out, x, self.gamma, post_slope)
+        return ops.scale_add(out, xr, self.gamma, post_slope)
 
 
 class ImgAttConvBlock(nn.Module):

@@ -728,6 +728,126 @@ def linear(x, w, bias=None, pre_slope=1.0):
 
 
 # --------------------------------------------------------------------------------------------
+# grouped linears (many nn.Linear on one shared input: the style projections of the AdaIN blocks)
+# --------------------------------------------------------------------------------------------
+class _GemmJob(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("ldc", ctypes.c_int32),
+                ("sAi", ctypes.c_int64), ("sAk", ctypes.c_int64), ("sBk", ctypes.c_int64), ("sBj", ctypes.c_int64),
+                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+_GEMM_TABLES = collections.OrderedDict()   # job-list signature -> (device jobs, device tiles, n_tiles, pinned host copies)
+
+
+def _gemm_tables(jobs, col_tiles_only=False):
+    """Device job / tile tables of a grouped launch (include/gim_hip.h gim_gemm_job), cached by their content: the operands are
+    parameters, their .grad buffers and allocator blocks whose addresses repeat from step to step."""
+    sig = (tuple(jobs), col_tiles_only)
+    ent = _GEMM_TABLES.get(sig)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("grouped linears: a job table not seen before; run eager warm-up steps before capturing a hipGraph")
+        arr = (_GemmJob * len(jobs))()
+        tiles = []
+        for j, jb in enumerate(jobs):
+            a = arr[j]
+            (a.A, a.B, a.C, a.bias, a.M, a.N, a.K, a.ldc, a.sAi, a.sAk, a.sBk, a.sBj, a.flags) = jb
+            for it in range(1 if col_tiles_only else (jb[4] + 63) // 64):
+                for jt in range((jb[5] + 63) // 64):
+                    tiles.append((j, it, jt))
+        hj = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
+        ht = torch.tensor(tiles, dtype=torch.int32).pin_memory()
+        dev = torch.device("cuda", torch._C._cuda_getDevice())
+        ent = _GEMM_TABLES[sig] = (hj.to(dev, non_blocking=True), ht.to(dev, non_blocking=True), len(tiles), (hj, ht))
+        while len(_GEMM_TABLES) > 64:
+            _GEMM_TABLES.popitem(last=False)
+    else:
+        _GEMM_TABLES.move_to_end(sig)
+    return ent
+
+
+class GroupedLinearFn(Function):
+    """(y_0, ..., y_{n-1}) with y_g = x @ w_g^T + b_g for n nn.Linear layers on ONE input x [M, K]: one launch forward, and one
+    grouped product + one grouped column sum backward (dx = sum_g dy_g @ w_g with float atomics into a zeroed buffer, dw_g =
+    dy_g^T @ x and db_g added straight into the optimizer's gradient bucket where it exists).  Replaces 3 x n launches of 5-7 us
+    (the 36 style projections of the generator: models/model_blocks.py:786-789,829-832) and the n - 1 autograd additions of dx."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        lib = _lib.load()
+        x = _req(x, "x")
+        M, K = x.shape
+        ws, bs = wb[0::2], wb[1::2]
+        for w in ws:
+            if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == K and w.is_contiguous()):
+                raise RuntimeError("grouped linear: weights must be contiguous CUDA float32 [out, %d]" % K)
+        sizes = [w.shape[0] for w in ws]
+        buf = torch.empty(M * sum(sizes), device=x.device, dtype=torch.float32)
+        ys, off = [], 0
+        for n_ in sizes:
+            ys.append(buf[off:off + M * n_].view(M, n_))
+            off += M * n_
+        jobs = [(_p(x), _p(w), _p(y), _p(b) or 0, M, n_, K, n_, K, 1, 1, K, 0) for w, b, y, n_ in zip(ws, bs, ys, sizes)]
+        dj, dt, nt, _ = _gemm_tables(jobs)
+        check(lib.gim_bgemm_grouped(dj.data_ptr(), dt.data_ptr(), nt, _stream()), "bgemm_grouped")
+        if _FLOPS is not None:
+            for n_ in sizes:
+                ent = _FLOPS.setdefault(("bgemm", (1, M, n_, K)), [0, 2.0 * M * n_ * K])
+                ent[0] += 1
+        ctx.save_for_backward(x, *wb)
+        return tuple(ys)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        x, *wb = ctx.saved_tensors
+        ws, bs = wb[0::2], wb[1::2]
+        M, K = x.shape
+        st = _stream()
+        need_x = ctx.needs_input_grad[0]
+        dx = torch.zeros((M, K), device=x.device, dtype=torch.float32) if need_x else None
+        jobs, cjobs, grads = [], [], []
+        for g, (w, b, dy) in enumerate(zip(ws, bs, dys)):
+            gw = gb = None
+            if dy is not None:
+                dy = _req(dy, "dy")
+                n_ = w.shape[0]
+                if need_x:      # dx += dy_g @ w_g : A = dy_g [M, n], B(k = n, j) = w_g[k][j]
+                    jobs.append((_p(dy), _p(w), _p(dx), 0, M, K, n_, K, n_, 1, K, 1, 2))
+                if ctx.needs_input_grad[1 + 2 * g]:   # dw_g = dy_g^T @ x : A(i = n, k = m) = dy_g[m][i], B(k = m, j) = x[k][j]
+                    tgt = _grad_target(w)
+                    if tgt is None:
+                        gw = torch.empty_like(w)
+                    jobs.append((_p(dy), _p(x), _p(tgt if tgt is not None else gw), 0, n_, K, M, K, 1, n_, K, 1, 1 if tgt is not None else 0))
+                if b is not None and ctx.needs_input_grad[2 + 2 * g]:
+                    tgt = _grad_target(b)
+                    if tgt is None:
+                        gb = torch.empty_like(b)
+                    cjobs.append((_p(dy), 0, _p(tgt if tgt is not None else gb), 0, M, n_, 0, 0, n_, 1, 0, 0, 1 if tgt is not None else 0))
+                if _FLOPS is not None:
+                    ent = _FLOPS.setdefault(("bgemm", (1, M, n_, K)), [0, 2.0 * M * n_ * K])
+                    ent[0] += 2
+            grads += [gw, gb]
+        if jobs:
+            dj, dt, nt, _ = _gemm_tables(jobs)
+            check(lib.gim_bgemm_grouped(dj.data_ptr(), dt.data_ptr(), nt, st), "bgemm_grouped")
+        if cjobs:
+            dj, dt, nt, _ = _gemm_tables(cjobs, col_tiles_only=True)
+            check(lib.gim_colsum_grouped(dj.data_ptr(), dt.data_ptr(), nt, st), "colsum_grouped")
+        return (dx, *grads)
+
+
+def grouped_linear(x, layers):
+    """[y_g] for the (weight, bias) pairs in `layers`, all applied to x [M, K]."""
+    flat = []
+    for w, b in layers:
+        flat += [w, b]
+    return GroupedLinearFn.apply(x, *flat)
+
+
+# --------------------------------------------------------------------------------------------
 # instance norm / AdaIN
 # --------------------------------------------------------------------------------------------
 class NormFn(Function):
@@ -843,6 +963,82 @@ class AvgPool2BwdFn(Function):
     @staticmethod
     def backward(ctx, g):
         return AvgPool2Fn.apply(g), None
+
+
+class ForkFn(Function):
+    """n aliases of x for n consumers.  Autograd sums the gradients of a tensor with several consumers pairwise - one launch and one
+    full read-modify-write per extra consumer; here each consumer gets an alias of its own and the backward adds all incoming
+    gradients in ONE kernel (gim_add_n).  Under create_graph (the R1 term) the sum is built from differentiable additions."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if _second_order():
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        lib = _lib.load()
+        gs = [_req(g, "g") for g in gs]
+        out = torch.empty_like(gs[0])
+        cur, rest = gs[0], gs[1:]
+        while rest:
+            take, rest = rest[:3], rest[3:]
+            ptrs = [_p(t) for t in take] + [None] * (3 - len(take))
+            check(lib.gim_add_n(_p(cur), ptrs[0], ptrs[1], ptrs[2], _p(out), out.numel(), _stream()), "add_n")
+            cur = out
+        return out, None
+
+
+def fork(x, n):
+    return ForkFn.apply(x, n) if (n > 1 and x.requires_grad and torch.is_grad_enabled()) else (x,) * n
+
+
+class ForkPoolFn(Function):
+    """(alias of x, avgpool2(x)) for the two consumers of a ResBlockDown's input (conv path / pooled skip path); the backward
+    adds the conv path's gradient and the un-pooled skip gradient in one kernel (instead of avgpool2_bwd + an autograd addition)."""
+
+    @staticmethod
+    def forward(ctx, x, in_slope):
+        lib = _lib.load()
+        x = _req(x, "x")
+        N, H, W, C = x.shape
+        y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
+        if in_slope != 1.0:
+            check(lib.gim_avgpool2_fwd_act(_p(x), _p(y), N, H, W, C, in_slope, _stream()), "avgpool2_fwd_act")
+        else:
+            check(lib.gim_avgpool2_fwd(_p(x), _p(y), N, H, W, C, _stream()), "avgpool2_fwd")
+        ctx.cfg = (N, H, W, C)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g, dyp):
+        if dyp is None:
+            return g, None
+        if g is None or _second_order():
+            gp = AvgPool2BwdFn.apply(dyp, ctx.cfg)
+            return (gp if g is None else g + gp), None
+        lib = _lib.load()
+        N, H, W, C = ctx.cfg
+        g, dyp = _req(g, "g"), _req(dyp, "dy")
+        out = torch.empty_like(g)
+        check(lib.gim_add_avgpool2_bwd(_p(g), _p(dyp), _p(out), N, H, W, C, _stream()), "add_avgpool2_bwd")
+        return out, None
+
+
+def fork_pool(x, in_slope=1.0):
+    """(x for the conv path, avgpool2(x) for the skip path) - see ForkPoolFn; plain pooling when x carries no gradient."""
+    if x.requires_grad and torch.is_grad_enabled():
+        return ForkPoolFn.apply(x, in_slope)
+    return x, AvgPool2Fn.apply(x, in_slope)
 
 
 class MaxPoolLreluFn(Function):

@@ -430,19 +430,19 @@ def test_trainer_protocol_vs_reference_golden(tag):
     assert n_checked > 600, n_checked
 
 
-def _assert_one_adam_step_matches_oracle(params, buffers, otr, lrs, beta2=0.99, max_share=1e-3, noise_lr=1e-4):
-    """One Adam update with beta1 = 0 moves an element by lr * g / (|g| + eps): by ~lr * sign(g) wherever the gradient is above
+def _adam_step_off_shares(params, otr, lrs, beta2=0.99, noise_lr=1e-4):
+    """{(agent, key): (share of compared elements whose update is more than 0.05 lr off the oracle's, largest difference, count)}.
+    One Adam update with beta1 = 0 moves an element by lr * g / (|g| + eps): by ~lr * sign(g) wherever the gradient is above
     rounding noise.  So compare ELEMENTWISE where the oracle's gradient element is not negligible inside its tensor (>= 1e-3 of
-    the tensor's rms; |g| is recovered from the oracle's second moment v = (1 - beta2) g^2): there the product's new value must
-    be the oracle's to a small fraction of one step.  No tensor is exempted except those whose whole gradient is mathematically
-    zero (a conv bias in front of a norm layer: pure rounding noise in fp64 and fp32 alike)."""
+    the tensor's rms; |g| is recovered from the oracle's second moment v = (1 - beta2) g^2).  No tensor is exempted except those
+    whose whole gradient is mathematically zero (a conv bias in front of a norm layer: pure rounding noise in fp64 and fp32 alike)."""
     gmax = max(float(st["v"].max()) for opt in (otr.au_opt, otr.im_opt) for st in opt.state.values()) ** 0.5 / (1 - beta2) ** 0.5
-    checked = 0
+    out = {}
     for name, sd_o, opt_o in (("au", otr.au_sd, otr.au_opt), ("im", otr.im_sd, otr.im_opt)):
         for kk, p in params[name].items():
             if kk not in opt_o.state:
                 continue
-            gabs = (opt_o.state[kk]["v"] / (1 - beta2)).sqrt()
+            gabs = (opt_o.state[kk]["v"] / (1 - beta2)).sqrt().double()
             rms = float(gabs.square().mean().sqrt())
             if rms < 1e-9 * gmax:
                 continue
@@ -451,13 +451,19 @@ def _assert_one_adam_step_matches_oracle(params, buffers, otr, lrs, beta2=0.99, 
             mask = (gabs > 1e-3 * rms) & (gabs > 1e-6)
             if not bool(mask.any()):
                 continue
-            diff = (p.detach().double().cpu() - sd_o[kk].detach()).abs()[mask]
-            off = float((diff > 0.05 * lr).double().mean())
-            assert off < max_share, (name, kk, "share of elements whose update differs from the oracle's", off, float(diff.max()))
-            checked += int(mask.sum())
+            diff = (p.detach().double().cpu() - sd_o[kk].detach().double()).abs()[mask]
+            out[(name, kk)] = (float((diff > 0.05 * lr).double().mean()), float(diff.max()), int(mask.sum()))
+    return out
+
+
+def _assert_one_adam_step_matches_oracle(params, buffers, otr, lrs, beta2=0.99, max_share=1e-3, noise_lr=1e-4):
+    shares = _adam_step_off_shares(params, otr, lrs, beta2, noise_lr)
+    for (name, kk), (off, dmax, _) in shares.items():
+        assert off < max_share, (name, kk, "share of elements whose update differs from the oracle's", off, dmax)
+    for name, sd_o in (("au", otr.au_sd), ("im", otr.im_sd)):
         for kk, b in buffers[name].items():
             assert relerr(b, sd_o[kk]) < 1e-3, (name, kk)
-    assert checked > 50000
+    assert sum(v[2] for v in shares.values()) > 50000
 
 
 @pytest.mark.parametrize("reg_param", [0.0, 10.0])
@@ -919,21 +925,36 @@ def test_two_rank_data_parallel_step_on_gpu(tmp_path):
     is_buf = lambda k_: k_.endswith(("weight_u", "weight_v"))   # noqa: E731
     params = {nm: {k_[3:]: v for k_, v in dp1["state"].items() if k_.startswith(nm + ".") and not is_buf(k_)} for nm in ("au", "im")}
     bufs = {nm: {k_[3:]: v for k_, v in dp1["state"].items() if k_.startswith(nm + ".") and is_buf(k_)} for nm in ("au", "im")}
-    # (two ranks sum their halves of the batch before the update: one more rounding than the single-process sum, and the first
-    # decoder block - whose input passes InstanceNorm on a 1x1 map, SURVEY F6 / F7 - carries enough near-zero gradient elements
-    # that 0.2 % of them change sign; allow 0.5 %)
-    _assert_one_adam_step_matches_oracle(params, bufs, otr, lrs, max_share=5e-3)
+    # Floor of this comparison, MEASURED here: the reference's own arithmetic in fp32 (the oracle run in float32 on the CPU, same
+    # inputs) against its fp64 run, by the same elementwise measure.  The first decoder block - whose input passes InstanceNorm on
+    # a 1x1 map, SURVEY F6 / F7 - carries near-zero gradient elements whose sign rounding decides.  Two ranks add one more
+    # rounding (their halves are summed before the update): the bound is 3x the fp32 oracle's worst tensor, at least 1e-3.
+    otr32 = go.OracleTrainer({k_: v.float() for k_, v in filled_sd(keys["au"], "dpg/au/").items()},
+                             {k_: v.float() for k_, v in filled_sd(keys["im"], "dpg/im/").items()}, n, lrs["au"], lrs["im"], 1e-4)
+    otr32.step(*[t.float() for t in (leaked, real, si, z)])
+    p32 = {nm: {k_: v for k_, v in sd_.items() if go.is_param(k_)} for nm, sd_ in (("au", otr32.au_sd), ("im", otr32.im_sd))}
+    floor = max(v[0] for v in _adam_step_off_shares(p32, otr, lrs).values())
+    print("fp32 oracle vs fp64 oracle: worst share of elements off by > 0.05 lr after one Adam step: %.2e" % floor)
+    _assert_one_adam_step_matches_oracle(params, bufs, otr, lrs, max_share=max(3 * floor, 1e-3))
     # --- two iterations: data-parallel == single process on the whole batch, up to the order of the float atomics
-    a, b = run(1, str(tmp_path / "single.pt"), 2), run(2, str(tmp_path / "dp2.pt"), 2)
+    # Floor, MEASURED here: the single-process run against ITSELF (the float atomics of the weight-gradient slices combine in a
+    # different order from run to run).  Zero-gradient biases random-walk by +-lr per update; in a few generator conv weights
+    # ~1e-4 of the elements have gradients at rounding level, and each such element whose sign differs between two summation
+    # orders ends 2 * lr apart after an Adam(beta1 = 0) step.  Data-parallel adds the order of the cross-rank sum: its distance from
+    # a single-process run must stay within 3x the run-to-run spread of the single process, per tensor class (never below the
+    # 2 * lr * sqrt(1e-4) ~ 2e-5-of-the-norm effect of one more reordering: floors of 2e-3 / 1e-2 for weights / biases).
+    a, a2, b = run(1, str(tmp_path / "single.pt"), 2), run(1, str(tmp_path / "single2.pt"), 2), run(2, str(tmp_path / "dp2.pt"), 2)
+    spread = {True: 0.0, False: 0.0}
+    for k_ in a["state"]:
+        spread[k_.endswith(".bias")] = max(spread[k_.endswith(".bias")], relerr(a2["state"][k_], a["state"][k_]))
+    print("single-process run-to-run spread: weights %.2e, biases %.2e" % (spread[False], spread[True]))
     bad = []
     for k_ in a["state"]:
         e = relerr(b["state"][k_], a["state"][k_])
-        # zero-gradient biases random-walk by +-lr (see the overlap test); in a few generator conv weights up to ~1e-4 of the
-        # elements have gradients at rounding level, and each such element whose sign differs between the two summation orders
-        # ends 2 * lr apart after an Adam(beta1 = 0) step: observed 3e-3 ... 7e-3 of the tensor's norm over the round's runs
-        if e > (5.5e-2 if k_.endswith(".bias") else 1.5e-2):
+        isb = k_.endswith(".bias")
+        if e > max(3 * spread[isb], 1e-2 if isb else 2e-3):
             bad.append((k_, e))
-    assert not bad, bad[:5]
+    assert not bad, (bad[:5], spread)
 
 
 def test_authentication_eval_agents_on_episode_bank():
