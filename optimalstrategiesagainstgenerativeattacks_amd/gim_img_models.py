@@ -49,6 +49,7 @@ def _use_side_streams(t):
 _STREAM_MAP = [int(v) for v in os.environ.get("GIM_STREAM_MAP", "0,1,2,2,0").split(",")]
 assert len(_STREAM_MAP) == 5, "GIM_STREAM_MAP: five comma-separated stream ids (roles 0..4)"
 _POOL = {}
+GROUP_STYLE_LINEARS = [True]   # the generator's 36 style projections as one grouped launch (AdaInImage2Image.forward)
 
 
 def _role_stream(device, role):
@@ -240,9 +241,9 @@ class AdaInImage2Image(nn.Module):
             side = _side_streams(x.device)[0]
             ops.stream_wait(side, cur)
             with torch.cuda.stream(side):
-                if torch.cuda.is_current_stream_capturing():
-                    # (the grouped launch addresses its outputs and gradients through job tables built per allocation: under a
-                    #  hipGraph capture the layers run one by one)
+                if not GROUP_STYLE_LINEARS[0]:
+                    # (the grouped launch addresses its outputs and gradients through job tables built per allocation; a process
+                    #  that captures hipGraphs - graph.GraphedGimStep clears the switch before its warm-up - runs the layers one by one)
                     svs_res = [b.style_vectors(style) for b in self.adain_res_block.res_blocks]
                     svs_up = [b.style_vectors(style) for b in self.adain_up_block.up_blocks]
                 else:

@@ -26,6 +26,8 @@ class GraphedGimStep:
         self.mod = trainer.module
         self.static = [t.clone() for t in (leaked, real, si, z)]
         warmup = max(warmup, 3)  # the batched weight-gradient finish must have seen every job table it will capture
+        from . import gim_img_models
+        gim_img_models.GROUP_STYLE_LINEARS[0] = False   # warm-up and capture must launch the same kernels (see AdaInImage2Image.forward)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
