@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--min-gain", type=float, default=0.03)
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad", help="which kernel kinds to tune (comma separated)")
     ap.add_argument("--out", default=None, help="with --write: write the rows to this file instead of the compiled-in table")
+    ap.add_argument("--only-n", type=int, default=0, help="tune only the shapes with this many images")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     fwd, bwd = record_shapes(args.workload, args.batch)
@@ -73,6 +74,8 @@ def main():
     tot_auto = tot_best = 0.0
     for cfg, cnt in sorted(fwd.items(), key=lambda kv: -kv[1]):
         N, H, W, Cin, Cout, KH, ups, slope, pool, fold = cfg
+        if args.only_n and N != args.only_n:
+            continue
         narrow = bool(Cin % 16 or Cout % 16)   # generic-K layers (3 / 6 channels): forward / dgrad use the heuristics, wgrad is tuned
         n_dx = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dx)
         n_dw = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dw)
