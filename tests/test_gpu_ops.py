@@ -526,6 +526,38 @@ def test_conv_operands_beyond_2gib_are_split_over_the_batch():
     assert relerr(acc.view(Cout, Cin), ref) < 1e-4
 
 
+def test_deterministic_wgrad_slabs_switch():
+    """GIM_WGRAD_SLABS=1 (read at import: a child process): the non-queued weight-gradient path combines its pixel slices as slabs
+    + a fixed-order reduce instead of float atomics - the parity cases still pass, and two runs of one weight gradient are bit-equal."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from optimalstrategiesagainstgenerativeattacks_amd import ops\n"
+        "assert ops._WGRAD_SLABS\n"
+        "g = torch.Generator(device='cuda').manual_seed(1)\n"
+        "x = torch.randn(8, 32, 32, 32, device='cuda', generator=g)\n"
+        "w = (torch.randn(64, 32, 3, 3, device='cuda', generator=g) * 0.05).contiguous(memory_format=torch.channels_last)\n"
+        "r = torch.randn(8, 32, 32, 64, device='cuda', generator=g)\n"
+        "outs = []\n"
+        "for _ in range(2):\n"
+        "    wg = w.clone().requires_grad_()\n"
+        "    (ops.conv2d(x, wg, None, None, None, None, None, 0, 0.2) * r).sum().backward()\n"
+        "    outs.append(wg.grad.clone())\n"
+        "assert torch.equal(outs[0], outs[1]), 'slab combine is not run-to-run identical'\n"
+        "wd = w.double().requires_grad_()\n"
+        "(torch.nn.functional.conv2d(torch.nn.functional.leaky_relu(x.permute(0, 3, 1, 2).double(), 0.2), wd, padding=1) * r.permute(0, 3, 1, 2).double()).sum().backward()\n"
+        "err = float((outs[0].double() - wd.grad).norm() / wd.grad.norm())\n"
+        "assert err < 3e-5, err\n"
+        "print('ok', err)\n") % root
+    r_ = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GIM_WGRAD_SLABS="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        text=True, timeout=300)
+    assert r_.returncode == 0 and "ok" in r_.stdout, r_.stderr[-2000:]
+
+
 def test_failed_backward_leaves_no_stale_weight_gradient_jobs():
     """An exception inside autograd after some convs queued their weight-gradient jobs must not leak into the next iteration:
     FusedAdam.zero_grad() drops the jobs, re-zeroes the arena slots and re-arms the end-of-backward callback."""
