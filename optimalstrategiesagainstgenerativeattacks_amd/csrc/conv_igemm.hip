@@ -1410,6 +1410,92 @@ static void launch_wgrad(const WgP& p, int bm, int bn, int bk, dim3 g, hipStream
     else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 1, VA, VB, FASTB>), g, dim3(256), 0, st, p);
 }
 
+// Weight gradient of a 1x1 convolution with <= 8 channels on ONE side (the skip convs on images: 3 -> 64, 6 -> 64, 64 -> 3): an outer
+// product of a wide row (64+ channels) and a handful of scalars per pixel, summed over ~10^5 pixels - HBM-bound (the wide tensor is
+// read once: 21 MB at 80 images of 32 x 32 x 64), for which the MFMA kernel above needs 48-65 us (scalar gathers of the narrow
+// operand, 0.7 TFLOP/s).  Thread = one wide channel x one of 16 pixel phases, eight pixels in flight per thread (the loop is bound by
+// load latency, not by arithmetic); the narrow row is one address for the whole wave.  out[co][ci] (+ bias gradient), combined with
+// float atomics into the pre-zeroed arena slot like every other slice.
+constexpr int NARROW_PARTS = 16, NARROW_MPER = 512, NARROW_U = 8, NARROW_ROWS = NARROW_MPER / NARROW_PARTS;
+template <int CN, bool EXACT>   // EXACT: Cn == CN (the narrow rows of a round are one compile-time-strided block); else Cn <= CN
+__global__ __launch_bounds__(64 * NARROW_PARTS) void wgrad_1x1_narrow_kernel(const float* __restrict__ wide, const float* __restrict__ nar,
+                                                                             float* __restrict__ out, float* __restrict__ bias_out, int M, int Cw,
+                                                                             int Cn_, float slope_x, int wide_is_dy) {
+    __shared__ float red[NARROW_PARTS][9][64];
+    const int Cn = EXACT ? CN : Cn_;
+    const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the narrow rows go through scalar loads
+    const int c = blockIdx.y * 64 + lane, cc = min(c, Cw - 1);
+    const int m0 = blockIdx.x * NARROW_MPER, m1 = min(M, m0 + NARROW_MPER);
+    float acc[CN], bsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < CN; ++j) acc[j] = 0.f;
+    // wave `part` owns NARROW_ROWS consecutive pixels, NARROW_U per round (M is a multiple of NARROW_U: the host checks): branch-free,
+    // all loads of a round issue back to back
+    const int mw = m0 + part * NARROW_ROWS, me = min(m1, mw + NARROW_ROWS);
+    for (int mb = mw; mb < me; mb += NARROW_U) {
+        float wv[NARROW_U], nv[NARROW_U][CN];
+        const float* nrow = nar + (long long)mb * Cn;
+#pragma unroll
+        for (int u = 0; u < NARROW_U; ++u) {
+            wv[u] = wide[(long long)(mb + u) * Cw + cc];
+#pragma unroll
+            for (int j = 0; j < CN; ++j) nv[u][j] = nrow[u * Cn + (EXACT ? j : min(j, Cn - 1))];
+        }
+#pragma unroll
+        for (int u = 0; u < NARROW_U; ++u) {
+            float w_ = wv[u];
+            bsum += w_;
+            if (!wide_is_dy) w_ = fmaxf(w_, w_ * slope_x);          // the wide operand is x: leaky-relu (slope 1 = identity)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) {
+                float n_ = nv[u][j];
+                if (wide_is_dy) n_ = fmaxf(n_, n_ * slope_x);
+                acc[j] += w_ * n_;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[part][j][lane] = j < CN ? acc[j < CN ? j : 0] : 0.f;
+    red[part][8][lane] = bsum;
+    __syncthreads();
+    // the 16 partials are summed and added to the slot with CONSECUTIVE lanes on consecutive addresses (one cache line per wave-wide
+    // atomic): out[c][j] of a wide dy is read across the LDS rows, out[j][c] of a wide x is wave j as it stands; wave 8 = bias
+    if (wide_is_dy) {
+        const int t = threadIdx.x, cl = t / Cn, j = t - cl * Cn, cg = blockIdx.y * 64 + cl;
+        if (t < 64 * Cn && cg < Cw) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < NARROW_PARTS; ++q) v += red[q][j][cl];
+            atomicAdd(&out[(long long)cg * Cn + j], v);
+        } else if (part == 8 && bias_out && c < Cw) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < NARROW_PARTS; ++q) v += red[q][8][lane];
+            atomicAdd(&bias_out[c], v);
+        }
+    } else if (part < Cn && c < Cw) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NARROW_PARTS; ++q) v += red[q][part][lane];
+        atomicAdd(&out[(long long)part * Cw + c], v);
+    }
+    // narrow dy (64 -> 3): its bias gradient is the column sum of the narrow rows; the first workgroup column does it, 64 pixel
+    // phases per channel folded through LDS
+    if (bias_out && !wide_is_dy && blockIdx.y == 0) {
+        __syncthreads();
+        float sb = 0.f;
+        if (part < Cn)
+            for (int m = m0 + lane; m < m1; m += 64) sb += nar[(long long)m * Cn + part];
+        if (part < 8) red[0][part][lane] = sb;
+        __syncthreads();
+        if (threadIdx.x < Cn) {
+            float v = 0.f;
+            for (int q = 0; q < 64; ++q) v += red[0][threadIdx.x][q];
+            atomicAdd(&bias_out[threadIdx.x], v);
+        }
+    }
+}
+
 // prezeroed: the caller guarantees slabs / bias_slabs hold zeros (or a partial sum to add to): pixel slices are combined
 // with float atomics and nothing is cleared here (gim_conv2d_wgrad_acc).
 static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs, const gim_conv_shape* s,
@@ -1443,6 +1529,24 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     if (atomic && !prezeroed && !t_plan_out) {
         (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
         if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
+    }
+    // 1x1 convolution with <= 8 channels on one side, atomic combine: the outer-product kernel (no table row: nothing to choose)
+    if (s->KH == 1 && !s->wfold && !s->ups && !s->pool && atomic && (s->Cin <= 8 || s->Cout <= 8) && (s->Cin >= 16 || s->Cout >= 16) && q.M % NARROW_U == 0 &&
+        s->tune_tile == 0 && s->tune_wgrad == 0) {   // an explicit tile / slice choice of the caller means the MFMA kernel
+        const bool wide_is_dy = s->Cin <= 8;
+        const int Cw = wide_is_dy ? s->Cout : s->Cin, Cn = wide_is_dy ? s->Cin : s->Cout;
+        const int nsl = (q.M + NARROW_MPER - 1) / NARROW_MPER;
+        if (t_plan_out) {
+            const int32_t v[8] = {0, 0, 0, nsl, nsl, (Cw + 63) / 64, 1, 0};
+            for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
+            return GIM_OK;
+        }
+        const dim3 g(nsl, (Cw + 63) / 64), b(64 * NARROW_PARTS);
+        const float *wd = wide_is_dy ? dy : x, *nr = wide_is_dy ? x : dy;
+        if (Cn == 3) hipLaunchKernelGGL((wgrad_1x1_narrow_kernel<3, true>), g, b, 0, (hipStream_t)stream, wd, nr, slabs, bias_slabs, q.M, Cw, Cn, s->pre_slope, wide_is_dy ? 1 : 0);
+        else if (Cn == 6) hipLaunchKernelGGL((wgrad_1x1_narrow_kernel<6, true>), g, b, 0, (hipStream_t)stream, wd, nr, slabs, bias_slabs, q.M, Cw, Cn, s->pre_slope, wide_is_dy ? 1 : 0);
+        else hipLaunchKernelGGL((wgrad_1x1_narrow_kernel<8, false>), g, b, 0, (hipStream_t)stream, wd, nr, slabs, bias_slabs, q.M, Cw, Cn, s->pre_slope, wide_is_dy ? 1 : 0);
+        return gim_check_launch("gim_conv2d_wgrad");
     }
     p.ns = q.ns;
     p.xcd = (q.ns >= 64 || (q.ns >= 8 && q.ns % 8 == 0)) ? 1 : 0;   // every XCD gets (nearly) the same number of slices

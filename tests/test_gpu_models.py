@@ -937,23 +937,36 @@ def test_two_rank_data_parallel_step_on_gpu(tmp_path):
     print("fp32 oracle vs fp64 oracle: worst share of elements off by > 0.05 lr after one Adam step: %.2e" % floor)
     _assert_one_adam_step_matches_oracle(params, bufs, otr, lrs, max_share=max(3 * floor, 1e-3))
     # --- two iterations: data-parallel == single process on the whole batch, up to the order of the float atomics
-    # Floor, MEASURED here: the single-process run against ITSELF (the float atomics of the weight-gradient slices combine in a
-    # different order from run to run).  Zero-gradient biases random-walk by +-lr per update; in a few generator conv weights
-    # ~1e-4 of the elements have gradients at rounding level, and each such element whose sign differs between two summation
-    # orders ends 2 * lr apart after an Adam(beta1 = 0) step.  Data-parallel adds the order of the cross-rank sum: its distance from
-    # a single-process run must stay within 3x the run-to-run spread of the single process, per tensor class (never below the
-    # 2 * lr * sqrt(1e-4) ~ 2e-5-of-the-norm effect of one more reordering: floors of 2e-3 / 1e-2 for weights / biases).
+    # What bounds this comparison, MEASURED (profiles/r03_g_dp_run_to_run_spread.txt: two single-process and two 2-rank runs of this
+    # very configuration, all four pairs): the float atomics of the weight-gradient slices combine in a different order from run to
+    # run, so after iteration 1 a few elements whose gradient is at rounding level end up to 2 * lr apart (Adam, beta1 = 0: the update
+    # is lr * sign-like); iteration 2 then runs on weights that differ by ~1e-4 of their norm, which moves every gradient by 1e-4 ..
+    # 1e-3 of its typical size - and the 1-5 % of a tensor's elements whose gradient is that small against the rest move by
+    # 0.05 .. 2 lr.  The spread between two runs of the SAME program is therefore heavy-tailed: 1e-4 ... 3.3e-3 of the tensor norm in
+    # the four pairs of that profile (the largest pair was two runs of the 2-rank program), and one sample of it is no floor.  The
+    # comparison is made on what a data-parallel error would change and this noise does not: a rank's gradient missing or weighted
+    # wrongly moves MOST elements by the order of lr (relative error >= 1e-2 at these weight scales, > 30 % of the elements beyond
+    # lr / 2); the noise leaves < 0.5 % of a tensor's elements beyond lr / 2.  Bounds: share of elements beyond lr / 2 below 2 %,
+    # tensor error below 1e-2 (weights) / 3x the measured spread, at least 1e-2 (biases: zero-gradient biases random-walk by +-lr
+    # per update, a stable statistic).  The one-iteration comparison above is the strict one (against the fp64 oracle).
     a, a2, b = run(1, str(tmp_path / "single.pt"), 2), run(1, str(tmp_path / "single2.pt"), 2), run(2, str(tmp_path / "dp2.pt"), 2)
     spread = {True: 0.0, False: 0.0}
     for k_ in a["state"]:
         spread[k_.endswith(".bias")] = max(spread[k_.endswith(".bias")], relerr(a2["state"][k_], a["state"][k_]))
     print("single-process run-to-run spread: weights %.2e, biases %.2e" % (spread[False], spread[True]))
-    bad = []
+    bad, worst = [], (0.0, 0.0)
     for k_ in a["state"]:
         e = relerr(b["state"][k_], a["state"][k_])
         isb = k_.endswith(".bias")
-        if e > max(3 * spread[isb], 1e-2 if isb else 2e-3):
-            bad.append((k_, e))
+        if isb or is_buf(k_):
+            if e > max(3 * spread[isb], 1e-2):
+                bad.append((k_, e))
+            continue
+        share = float(((b["state"][k_] - a["state"][k_]).abs() > 0.5e-3).double().mean())
+        worst = (max(worst[0], e), max(worst[1], share))
+        if e > 1e-2 or share > 2e-2:
+            bad.append((k_, e, share))
+    print("2-rank vs single process after two iterations: worst weight tensor error %.2e, worst share beyond lr / 2 %.2e" % worst)
     assert not bad, (bad[:5], spread)
 
 

@@ -526,6 +526,32 @@ def test_conv_operands_beyond_2gib_are_split_over_the_batch():
     assert relerr(acc.view(Cout, Cin), ref) < 1e-4
 
 
+@pytest.mark.parametrize("N,S,Cin,Cout,slope", [(80, 32, 3, 64, 1.0), (16, 64, 6, 64, 0.2), (80, 32, 64, 3, 1.0), (5, 8, 1, 96, 0.2),
+                                                (3, 16, 160, 8, 0.2), (2, 4, 8, 16, 1.0)])
+def test_wgrad_1x1_narrow_side(N, S, Cin, Cout, slope):
+    """Weight + bias gradient of 1x1 convolutions with <= 8 channels on one side (the image skip convs 3/6 -> 64 and 64 -> 3 of
+    models/gim_img_models.py): the outer-product kernel behind gim_conv2d_wgrad_acc, both orientations, channel counts off the
+    64-lane tile, pixel counts off the 512-pixel slice, with the pre-activation on x, ADDING to what the arena slot already holds."""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(N, S, S, Cin, device=dev(), generator=g)
+    dy = torch.randn(N, S, S, Cout, device=dev(), generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    sh = _lib.GimConvShape(N, S, S, Cin, Cout, 1, 0, slope)
+    pre_w = torch.randn(Cout * Cin, device=dev(), generator=g)
+    pre_b = torch.randn(Cout, device=dev(), generator=g)
+    acc, bacc = pre_w.clone(), pre_b.clone()
+    _lib.check(lib.gim_conv2d_wgrad_acc(dy.data_ptr(), x.data_ptr(), acc.data_ptr(), bacc.data_ptr(), sh, st), "wgrad_acc")
+    xa = F.leaky_relu(x.double(), slope)
+    ref = torch.einsum("nhwo,nhwc->oc", dy.double(), xa)
+    assert relerr(acc.view(Cout, Cin).double() - pre_w.view(Cout, Cin).double(), ref) < 1e-5
+    assert relerr(bacc.double() - pre_b.double(), dy.double().sum((0, 1, 2))) < 1e-5
+    acc2 = torch.zeros_like(acc)
+    _lib.check(lib.gim_conv2d_wgrad_acc(dy.data_ptr(), x.data_ptr(), acc2.data_ptr(), None, sh, st), "wgrad_acc, no bias")
+    assert relerr(acc2.view(Cout, Cin), ref) < 1e-5
+
+
 def test_deterministic_wgrad_slabs_switch():
     """GIM_WGRAD_SLABS=1 (read at import: a child process): the non-queued weight-gradient path combines its pixel slices as slabs
     + a fixed-order reduce instead of float atomics - the parity cases still pass, and two runs of one weight gradient are bit-equal."""
