@@ -151,6 +151,16 @@ int gim_conv2d_transpose_weights(const float* w, float* wt, int Cout, int Cin, i
 int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, const float* mask_x, float* dx,
                        const gim_conv_shape* shape, void* stream);
 
+/* The same gradient for PLAIN convolutions (no pool / ups / fold) with <= 8 input channels, x-folded: J horizontally adjacent dx
+ * pixels become the J * Cin output columns of one stride-(1, J) convolution of dy with K x (K + J - 1) taps - [N, H, W / J, J * Cin]
+ * is [N, H, W, Cin] in memory - so that the 16-column MFMA tile carries 12 useful columns (Cin = 3: J = 4; Cin = 6: J = 2) instead of
+ * 3 or 6.  gim_conv2d_xfold_weights builds WX[(j, ci)][a][u][co] = W[co][K-1-a][K-1-(u-j)][ci] (0 outside 0 <= u-j < K; J * Cin * K *
+ * (K + J - 1) * Cout floats) once per weight update.  J: power of two dividing W, J * Cin <= 32; Cout % 16 == 0.
+ * (F.conv2d's backward w.r.t. the input images, autograd of training/gim_img_training.py:164,176.) */
+int gim_conv2d_xfold_weights(const float* w, float* wx, int Cout, int Cin, int KH, int J, void* stream);
+int gim_conv2d_dgrad_xfold(const float* dy, const float* wx, const float* sigma, const float* mask_x, float* dx,
+                           const gim_conv_shape* shape, int J, void* stream);
+
 /* Introspection (tests, tools/conv_autotune.py): the launch an entry point would make for `shape`, nothing is launched.
  *   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
  *   out[8] = {1 if a row of the compiled-in per-shape launch table matched, tile rows, tile columns, split-K factor

@@ -75,6 +75,8 @@ SIGNATURES = {
     "gim_conv_launch_plan": [SP, c_int, P],
     "gim_conv2d_transpose_weights": [P, P, c_int, c_int, c_int, P],
     "gim_conv2d_dgrad_t": [P, P, P, P, P, SP, P],
+    "gim_conv2d_xfold_weights": [P, P, c_int, c_int, c_int, c_int, P],
+    "gim_conv2d_dgrad_xfold": [P, P, P, P, P, SP, c_int, P],
     "gim_episode_gather": [P, P, P, P, c_int, c_int, c_int, c_int, P],
     "gim_maxpool_gather": [P, P, P, P, c_int, c_int, c_int, c_float, P],
     "gim_softmax_dim1_bwd_dp": [P, P, P, P, c_int, c_int, c_int, P],

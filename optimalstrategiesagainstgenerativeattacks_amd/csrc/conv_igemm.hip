@@ -36,9 +36,11 @@ struct Geo {
     int Hin, Win;             // stored size of the gathered tensor (before the on-the-fly nearest upsample)
     int ups;                  // gathered coordinates are >> ups
     int s_in;                 // gather stride (1 or 2)
+    int s_in_x;               // ... along x (= s_in except in the x-folded dgrad: stride J along x, 1 along y)
     int off_y, off_x;         // iy = oy * s_in + ta + off_y
     int Th, Tw;               // taps per dimension
     int KF;                   // taps per dimension of the weight tensor in memory
+    int KFw;                  // ... along x (= KF except in the x-folded dgrad: K + J - 1)
     int wa_base, wa_step, wb_base, wb_step;  // weight tap (a, b) = (wa_base + wa_step * ta, wb_base + wb_step * tb)
     int os, py, px;           // output pixel = (oy * os + py, ox * os + px) in an (H*os) x (W*os) image
     int pc, pc_kind, pc_K;    // PC mode: blockIdx.z & 3 = class; class parameters derived in the kernel
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
     const int n0 = blockIdx.y * BN;
     const int arow = t / QPR, aq = (t % QPR) * 4;
     const int He = g.Hin << g.ups, We = g.Win << g.ups;  // extent of the (virtually upsampled) gathered image
-    const int KF2 = g.KF * g.KF;
+    const int KF2 = g.KF * g.KFw;
 
     // per-row constants of the A gather: pixel origin (for the bounds test) and element offset without the tap
     int a_oy[A_ROWS], a_ox[A_ROWS];
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
         a_ok[i] = m < p.M;
         const int n = m >> (g.logH + g.logW);
         a_oy[i] = ((m >> g.logW) & (g.H - 1)) * g.s_in + g.off_y;
-        a_ox[i] = (m & (g.W - 1)) * g.s_in + g.off_x;
+        a_ox[i] = (m & (g.W - 1)) * g.s_in_x + g.off_x;
         a_off[i] = (long long)n * g.Hin * g.Win * p.Ca + (GEN ? 0 : aq);
         if (!g.ups) a_off[i] += ((long long)a_oy[i] * g.Win + a_ox[i]) * p.Ca;
     }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
             const int m = min(m0 + arow + RP * i, p.M - 1);
             const int n = m >> (g.logH + g.logW);
             a_oy[i] = ((m >> g.logW) & (g.H - 1)) * g.s_in + g.off_y;
-            a_ox[i] = (m & (g.W - 1)) * g.s_in + g.off_x;
+            a_ox[i] = (m & (g.W - 1)) * g.s_in_x + g.off_x;
             a_base[i] = (unsigned)((n * g.Hin * g.Win * p.Ca + aq) * 4);
             a_cur[i] = BUF_OOB;
         }
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
     auto load_tiles = [&](int k0) {
         if constexpr (!GEN) {
             const int ta = k_ta, tb = k_tb, c0 = k_c0;
-            const int wtap = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
+            const int wtap = (g.wa_base + g.wa_step * ta) * g.KFw + g.wb_base + g.wb_step * tb;
             // ---- A: gathered activations (offsets of this tap are in a_cur; the channel offset is wave-uniform) ----
             const unsigned sa = (unsigned)(c0 * 4);
 #pragma unroll
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
                             if (kf < p.Ktot) {
                                 const int tap = kf / p.Ca, c = kf - tap * p.Ca;
                                 const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
-                                const int wt = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
+                                const int wt = (g.wa_base + g.wa_step * ta) * g.KFw + g.wb_base + g.wb_step * tb;
                                 val[e] = p.w[b_off0[i] - aq + (long long)wt * p.Cin_w + c];
                             }
                         }
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
                     const int tap = kf / p.Ca;
                     const int ca = kf - tap * p.Ca;
                     const int ta = tap / g.Tw, tb = tap - ta * g.Tw;
-                    const int wt = (g.wa_base + g.wa_step * ta) * g.KF + g.wb_base + g.wb_step * tb;
+                    const int wt = (g.wa_base + g.wa_step * ta) * g.KFw + g.wb_base + g.wb_step * tb;
                     v = v && kf < p.Ktot;
                     return ((long long)ca * KF2 + wt) * p.Cin_w;
                 };
@@ -1050,6 +1052,35 @@ extern "C" int gim_conv2d_transpose_weights(const float* w, float* wt, int Cout,
 }
 
 // -------------------------------------------------------------------------------------------------
+// x-folded transposed weights for the gradient w.r.t. images (<= 8 input channels).  J horizontally adjacent dx pixels share all
+// but J - 1 of their K input columns, so the J * Cin values dx[y][J x' + j][ci] are the output CHANNELS of one stride-(1, J)
+// convolution of dy with K x (K + J - 1) taps - and [N, H, W / J, J * Cin] IS [N, H, W, Cin] in memory:
+//   WX[(j, ci)][a][u][co] = W[co][K - 1 - a][K - 1 - (u - j)][ci]  if 0 <= u - j < K, else 0     (taps already flipped)
+// The 16-column MFMA tile then carries 12 useful columns (Cin = 3: J = 4, Cin = 6: J = 2) instead of 3 or 6.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xfold_weights_kernel(const float* __restrict__ w, float* __restrict__ wx, int Cout, int Cin, int K, int J) {
+    const int KW = K + J - 1;
+    const long long total = (long long)J * Cin * K * KW * Cout;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % Cout);
+        long long r = i / Cout;
+        const int u = (int)(r % KW); r /= KW;
+        const int a = (int)(r % K); r /= K;
+        const int ci = (int)(r % Cin), j = (int)(r / Cin);
+        const int b = u - j;
+        wx[i] = (b >= 0 && b < K) ? w[(((long long)co * K + (K - 1 - a)) * K + (K - 1 - b)) * Cin + ci] : 0.f;
+    }
+}
+
+extern "C" int gim_conv2d_xfold_weights(const float* w, float* wx, int Cout, int Cin, int KH, int J, void* stream) {
+    GIM_CHECK_ARG(w && wx && Cout > 0 && Cin > 0 && KH > 0 && (KH & 1) && J >= 2 && (J & (J - 1)) == 0, "xfold_weights: bad args");
+    const long long total = (long long)J * Cin * KH * (KH + J - 1) * Cout;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(xfold_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wx, Cout, Cin, KH, J);
+    return gim_check_launch("gim_conv2d_xfold_weights");
+}
+
+// -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
 static int check_shape(const gim_conv_shape* s) {
@@ -1075,7 +1106,7 @@ static Geo geo_plain(const gim_conv_shape* s, bool flip) {
     geo_grid(g, s->N, s->H, s->W);
     g.ups = flip ? 0 : s->ups;
     g.Hin = s->H >> g.ups; g.Win = s->W >> g.ups;
-    g.s_in = 1; g.off_y = g.off_x = -pad; g.Th = g.Tw = g.KF = s->KH;
+    g.s_in = g.s_in_x = 1; g.off_y = g.off_x = -pad; g.Th = g.Tw = g.KF = g.KFw = s->KH;
     g.wa_base = g.wb_base = flip ? s->KH - 1 : 0;
     g.wa_step = g.wb_step = flip ? -1 : 1;
     g.os = 1;
@@ -1088,7 +1119,7 @@ static Geo geo_s2(const gim_conv_shape* s, bool flip) {
     const int pad = (s->KH - 1) / 2, KF = s->KH + 1;
     geo_grid(g, s->N, s->H / 2, s->W / 2);
     g.Hin = s->H; g.Win = s->W; g.ups = 0;
-    g.s_in = 2; g.off_y = g.off_x = -pad; g.Th = g.Tw = g.KF = KF;
+    g.s_in = g.s_in_x = 2; g.off_y = g.off_x = -pad; g.Th = g.Tw = g.KF = g.KFw = KF;
     g.wa_base = g.wb_base = flip ? KF - 1 : 0;
     g.wa_step = g.wb_step = flip ? -1 : 1;
     g.os = 1;
@@ -1100,7 +1131,7 @@ static Geo geo_pc(const gim_conv_shape* s, int kind) {
     Geo g{};
     geo_grid(g, s->N, s->H / 2, s->W / 2);
     g.Hin = s->H / 2; g.Win = s->W / 2; g.ups = 0;
-    g.s_in = 1; g.Th = g.Tw = (s->KH + 1) / 2; g.KF = s->KH + 1;
+    g.s_in = g.s_in_x = 1; g.Th = g.Tw = (s->KH + 1) / 2; g.KF = g.KFw = s->KH + 1;
     g.os = 2; g.pc = 1; g.pc_kind = kind; g.pc_K = s->KH;
     return g;
 }
@@ -1328,6 +1359,51 @@ extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* si
 extern "C" int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, const float* mask_x, float* dx,
                                   const gim_conv_shape* s, void* stream) {
     return dgrad_impl(dy, wt, sigma, mask_x, dx, s, stream, true);
+}
+
+// dgrad of a plain convolution with <= 8 input channels on x-folded weights (gim_conv2d_xfold_weights): the forward kernel's
+// operand path over dy with stride (1, J), K x (K + J - 1) taps and J * Cin output columns.
+extern "C" int gim_conv2d_dgrad_xfold(const float* dy, const float* wx, const float* sigma, const float* mask_x, float* dx,
+                                      const gim_conv_shape* s, int J, void* stream) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    GIM_CHECK_ARG(dy && wx && dx, "conv dgrad (x-folded): null pointer");
+    GIM_CHECK_ARG(!s->ups && !s->pool && !s->wfold, "conv dgrad (x-folded): plain convolutions only");
+    GIM_CHECK_ARG(J >= 2 && (J & (J - 1)) == 0 && s->W % J == 0 && J * s->Cin <= 32, "conv dgrad (x-folded): J must be a power of two dividing W with J * Cin <= 32");
+    GIM_CHECK_ARG(s->Cout % BK == 0 && !((uintptr_t)dy & 15) && !((uintptr_t)wx & 15), "conv dgrad (x-folded): Cout % 16 == 0 and 16-byte aligned operands required");
+    {
+        const size_t yi = (size_t)s->H * s->W * s->Cout, xi = (size_t)s->H * s->W * s->Cin;
+        if (s->N > 1 && (xi > yi ? xi : yi) * s->N * sizeof(float) > BUF_MAX_BYTES) {
+            gim_conv_shape a = *s, b = *s;
+            a.N = s->N / 2; b.N = s->N - a.N;
+            rc = gim_conv2d_dgrad_xfold(dy, wx, sigma, mask_x, dx, &a, J, stream);
+            if (rc) return rc;
+            return gim_conv2d_dgrad_xfold(dy + a.N * yi, wx, sigma, mask_x ? mask_x + a.N * xi : nullptr, dx + a.N * xi, &b, J, stream);
+        }
+    }
+    ConvP p{};
+    p.zero = zero_page();
+    p.pos_inf = __builtin_inff();
+    const int pad = (s->KH - 1) / 2;
+    Geo g{};
+    geo_grid(g, s->N, s->H, s->W / J);
+    g.Hin = s->H; g.Win = s->W; g.ups = 0;
+    g.s_in = 1; g.s_in_x = J; g.off_y = g.off_x = -pad;
+    g.Th = g.KF = s->KH; g.Tw = g.KFw = s->KH + J - 1;
+    g.wa_base = g.wb_base = 0; g.wa_step = g.wb_step = 1;
+    g.os = 1;
+    p.g = g;
+    p.x = dy; p.w = wx; p.bias = nullptr; p.sigma = sigma; p.res = nullptr; p.mask_x = mask_x; p.y = dx;
+    p.Ca = s->Cout; p.Cb = J * s->Cin; p.Cin_w = s->Cout;
+    p.M = g.N * g.H * g.W; p.Ktot = g.Th * g.Tw * s->Cout;
+    p.x_bytes = (unsigned)((unsigned long long)s->N * s->H * s->W * s->Cout * 4ull);
+    p.pre_slope = 1.f; p.mask_slope = s->pre_slope; p.out_scale = 1.f; p.res_ups = 0; p.post_slope = 1.f;
+    const size_t y_elems = (size_t)s->N * s->H * s->W * s->Cin;
+    p.tune_kind = 5;   // no table rows: heuristics (or the caller's tune_* fields)
+    p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit; p.y_zeroed = s->out_zeroed;
+    launch_igemm<0, 0>(p, y_elems, (hipStream_t)stream);
+    if (t_plan_out) return GIM_OK;
+    return gim_check_launch("gim_conv2d_dgrad_xfold");
 }
 
 // wgrad roles.  plain: A = dy [N,H,W,Cout], B = gathered x.  pool: A = dy [N,H/2,W/2,Cout], B = x gathered with

@@ -512,21 +512,27 @@ class ConvFn(Function):
 
 _ACT_STORAGE = os.environ.get("GIM_NO_ACT_STORAGE") is None   # A/B switch (host side)
 _NARROW_DGRAD_T = os.environ.get("GIM_NO_NARROW_DGRAD_T") is None   # A/B switch (host side)
+_NARROW_XFOLD = os.environ.get("GIM_NO_NARROW_XFOLD") is None   # A/B switch (host side)
 _WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
 
 
-def _transposed(lib, w, wk, Cout, Cin, KF):
-    """WT[Cin][KF][KF][Cout] of the (plain or folded) weights `wk` of parameter `w`, recomputed only when the weights
-    changed (autograd version counter for torch-side writes, optim.weights_epoch for the fused Adam kernel)."""
+def _transposed(lib, w, wk, Cout, Cin, KF, xfold=0):
+    """WT[Cin][KF][KF][Cout] of the (plain or folded) weights `wk` of parameter `w` - or, xfold = J, the x-folded
+    WX[J * Cin][KF][KF + J - 1][Cout] of gim_conv2d_xfold_weights - recomputed only when the weights changed (autograd version
+    counter for torch-side writes, optim.weights_epoch for the fused Adam kernel)."""
     from . import optim
     key = (w._version, optim.weights_epoch(w))
-    slot = (w.data_ptr(), KF)
+    slot = (w.data_ptr(), KF, xfold)
     ent = _WT_CACHE.get(slot)
     raw = _stream()
     if ent is None or ent[0] != key or ent[4]() is not w:
         cur = torch.cuda.current_stream()
-        wt = torch.empty(Cin * KF * KF * Cout, device=wk.device, dtype=torch.float32)
-        check(lib.gim_conv2d_transpose_weights(_p(wk), _p(wt), Cout, Cin, KF, raw), "transpose_weights")
+        if xfold:
+            wt = torch.empty(xfold * Cin * KF * (KF + xfold - 1) * Cout, device=wk.device, dtype=torch.float32)
+            check(lib.gim_conv2d_xfold_weights(_p(wk), _p(wt), Cout, Cin, KF, xfold, raw), "xfold_weights")
+        else:
+            wt = torch.empty(Cin * KF * KF * Cout, device=wk.device, dtype=torch.float32)
+            check(lib.gim_conv2d_transpose_weights(_p(wk), _p(wt), Cout, Cin, KF, raw), "transpose_weights")
         ent = (key, wt, cur.record_event(), raw, weakref.ref(w, lambda _r, slot=slot: _WT_CACHE.pop(slot, None)),
                torch.cuda.is_current_stream_capturing())
         _WT_CACHE[slot] = ent
@@ -536,6 +542,12 @@ def _transposed(lib, w, wk, Cout, Cin, KF):
             cur.wait_event(ent[2])
         ent[1].record_stream(cur)
     return ent[1]
+
+
+def _xfold_factor(Cin, W):
+    """J of the x-folded dgrad: the largest power of two with J * Cin <= 16 (the 16-column MFMA tile), at most 4, dividing W."""
+    J = 4 if Cin <= 4 else 2
+    return J if (Cin <= 8 and W % J == 0 and W // J >= 1) else 0
 
 
 def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
@@ -552,6 +564,12 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
     # loads) for the gradient w.r.t. IMAGES (<= 8 input
     # channels: 3 / 6 / 1), where the k-major kernel falls back to scalar weight loads (output channels not a multiple of 4)
     if w is not None and Cout % 16 == 0 and not (ups and not fold) and Cin <= 8 and _NARROW_DGRAD_T:
+        J = _xfold_factor(Cin, W) if KH >= 3 and not (ups or pool or fold) and _NARROW_XFOLD else 0
+        if J:   # J adjacent dx pixels as the output columns of one stride-(1, J) convolution: 12 of 16 MFMA columns carry data
+            wx = _transposed(lib, w, wk, Cout, Cin, KH, xfold=J)
+            dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+            check(lib.gim_conv2d_dgrad_xfold(_p(dy), _p(wx), _p(sigma), _p(mask), _p(dx), sh, J, st), "conv2d_dgrad_xfold")
+            return dx
         wt = _transposed(lib, w, wk, Cout, Cin, KH + 1 if fold else KH)
         dx = _conv_out(sh, 2, key, tuple(x.shape), x.device)
         check(lib.gim_conv2d_dgrad_t(_p(dy), _p(wt), _p(sigma), _p(mask), _p(dx), sh, st), "conv2d_dgrad_t")

@@ -552,6 +552,34 @@ def test_wgrad_1x1_narrow_side(N, S, Cin, Cout, slope):
     assert relerr(acc2.view(Cout, Cin), ref) < 1e-5
 
 
+@pytest.mark.parametrize("N,S,Cin,Cout,K,J,slope", [(5, 16, 3, 64, 3, 4, 0.2), (3, 32, 6, 64, 9, 2, 0.2), (2, 8, 3, 32, 9, 8, 1.0), (4, 4, 1, 16, 3, 4, 0.2),
+                                                     (2, 64, 6, 64, 9, 4, 1.0), (3, 2, 8, 48, 3, 2, 0.2)])
+def test_dgrad_xfold_narrow_input(N, S, Cin, Cout, K, J, slope):
+    """Gradient w.r.t. images (<= 8 input channels) on x-folded weights (gim_conv2d_xfold_weights + gim_conv2d_dgrad_xfold: J adjacent
+    dx pixels as the output columns of one stride-(1, J) convolution of dy) against fp64 autograd of F.conv2d, with the 1/sigma
+    scale and the LeakyReLU mask; J up to the row width (one folded pixel per row), 16- and 32-column tiles."""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, S, S, Cin, device=dev(), generator=g)
+    dy = torch.randn(N, S, S, Cout, device=dev(), generator=g)
+    w = torch.randn(Cout, K, K, Cin, device=dev(), generator=g) / np.sqrt(K * K * Cin)     # channels-last weight memory
+    sigma = torch.tensor([1.7], device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    wx = torch.empty(J * Cin * K * (K + J - 1) * Cout, device=dev())
+    _lib.check(lib.gim_conv2d_xfold_weights(w.data_ptr(), wx.data_ptr(), Cout, Cin, K, J, st), "xfold_weights")
+    sh = _lib.GimConvShape(N, S, S, Cin, Cout, K, 0, slope)
+    dx = torch.full((N, S, S, Cin), float("nan"), device=dev())
+    mask = x if slope != 1.0 else None
+    _lib.check(lib.gim_conv2d_dgrad_xfold(dy.data_ptr(), wx.data_ptr(), sigma.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                          dx.data_ptr(), sh, J, st), "dgrad_xfold")
+    xr = x.double().permute(0, 3, 1, 2).cpu().requires_grad_()
+    wr = w.double().permute(0, 3, 1, 2).cpu()
+    yr = F.conv2d(F.leaky_relu(xr, slope) if slope != 1.0 else xr, wr / 1.7, padding=(K - 1) // 2)
+    (yr * dy.double().permute(0, 3, 1, 2).cpu()).sum().backward()
+    assert relerr(nchw(dx), xr.grad) < TOL
+
+
 def test_deterministic_wgrad_slabs_switch():
     """GIM_WGRAD_SLABS=1 (read at import: a child process): the non-queued weight-gradient path combines its pixel slices as slabs
     + a fixed-order reduce instead of float atomics - the parity cases still pass, and two runs of one weight gradient are bit-equal."""

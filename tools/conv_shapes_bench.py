@@ -78,7 +78,12 @@ def main():
         flops = ops.conv_executed_flops(N, H, W, Cin, Cout, KH, ups, pool, fold)      # what the kernels execute (folds!)
         algo = ops.conv_algorithmic_flops(N, H, W, Cin, Cout, KH)                      # the unfused reference op
         t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
-        if Cout % 16 == 0 and not (ups and not fold) and Cin <= 8:   # as ops._conv_dgrad
+        J = ops._xfold_factor(Cin, W) if (KH >= 3 and not (ups or pool or fold) and Cout % 16 == 0 and ops._NARROW_XFOLD) else 0
+        if J:   # as ops._conv_dgrad: x-folded gradient w.r.t. images
+            wx = torch.empty(J * Cin * KH * (KH + J - 1) * Cout, device=dev)
+            lib.gim_conv2d_xfold_weights(w.data_ptr(), wx.data_ptr(), Cout, Cin, KH, J, st)
+            t_d = time_ms(lambda: lib.gim_conv2d_dgrad_xfold(y.data_ptr(), wx.data_ptr(), None, None, dx.data_ptr(), sh, J, st)) if n_dx else 0.0
+        elif Cout % 16 == 0 and not (ups and not fold) and Cin <= 8:
             wt = torch.empty(Cin * KF * KF * Cout, device=dev)
             lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
             t_d = time_ms(lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
