@@ -38,6 +38,11 @@ def main():
         tr.do_global_step()
         gi, di = G.gim_step(trainer, leaked, real, si, z=z)
         outs.append((gi[0].item(), di[0].item(), di[4].item(), di[5].item()))
+        if os.environ.get("GIM_DP_DUMP_EACH") and rank == 0:   # diagnostic: the state after every iteration
+            torch.cuda.synchronize()
+            sd_it = {"au." + k_: v.cpu().clone() for k_, v in au.state_dict().items()}
+            sd_it.update({"im." + k_: v.cpu().clone() for k_, v in im.state_dict().items()})
+            torch.save(sd_it, out + ".it%d" % it)
     torch.cuda.synchronize()
     if rank == 0:
         sd = {"au." + k_: v.cpu() for k_, v in au.state_dict().items()}

