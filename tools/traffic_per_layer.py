@@ -1,0 +1,34 @@
+"""Per-layer L2-miss traffic from tools/traffic_per_layer.sh: FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE per launch of the
+conv kernel against the bytes of the operands touched once.    python tools/traffic_per_layer.py gpurun_out/<outdir>"""
+import csv
+import glob
+import os
+import sys
+
+root = sys.argv[1]
+
+
+def mean_kib(d):
+    vals = []
+    for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith(("void conv_igemm_kernel", "void conv_wgrad_kernel")):
+                vals.append(float(r["Counter_Value"]))
+    return sum(vals) / len(vals) if vals else float("nan")
+
+
+print("%-6s %-28s %9s %9s %9s | %9s %7s   (MB per launch; operands = x + w + y touched once)" % ("kind", "N,H,Cin,Cout,K,pool", "fetch x2", "write", "total", "operands", "ratio"))
+tot_t = tot_o = 0.0
+for d in sorted(glob.glob(os.path.join(root, "*_*"))):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d).split("_")
+    kind, (N, H, Cin, Cout, K, ups, reps, pool) = name[0], [int(v) for v in name[1:9]]
+    fetch, write = mean_kib(os.path.join(d, "FETCH_SIZE")) * 1024 * 2 / 1e6, mean_kib(os.path.join(d, "WRITE_SIZE")) * 1024 / 1e6
+    KF = K + 1 if pool else K
+    xb, yb, wb = N * H * H * Cin * 4 / 1e6, N * (H >> pool) ** 2 * Cout * 4 / 1e6, Cout * KF * KF * Cin * 4 / 1e6
+    ops = xb + yb + wb
+    print("%-6s %-28s %9.1f %9.1f %9.1f | %9.1f %7.2f" % (kind, "%d,%d,%d,%d,%d,%d" % (N, H, Cin, Cout, K, pool), fetch, write, fetch + write, ops, (fetch + write) / ops))
+    tot_t += fetch + write
+    tot_o += ops
+print("sum over these launches: %.0f MB against %.0f MB of operands: %.2fx" % (tot_t, tot_o, tot_t / tot_o))
