@@ -164,7 +164,8 @@ int gim_conv2d_dgrad_xfold(const float* dy, const float* wx, const float* sigma,
 /* Introspection (tests, tools/conv_autotune.py): the launch an entry point would make for `shape`, nothing is launched.
  *   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
  *   out[8] = {1 if a row of the compiled-in per-shape launch table matched, tile rows, tile columns, split-K factor
- *             (wgrad: pixel slices), grid x, y, z, 0 (one matrix path: v_mfma_f32_32x32x2_f32 / 16x16x4)}.
+ *             (wgrad: pixel slices), grid x, y, z, loop form: 0 = tap-major K loop, 1 = patch-resident (plain 3x3 layers: the input
+ *             patch of a tile stays in LDS for all nine taps; tune_tile + 20000 selects it explicitly)}.
  * A batch beyond the 32-bit buffer-offset range (the entry points then halve it) reports the plan of its last half. */
 int gim_conv_launch_plan(const gim_conv_shape* shape, int kind, int32_t* out);
 

@@ -646,6 +646,248 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
 }
 
 // -------------------------------------------------------------------------------------------------
+// Patch-resident form of the fast path for plain 3x3 convolutions (forward, dgrad on k-major or transposed weights).
+// The taps of a tile of BM consecutive output pixels (whole image rows, or part of one) read the same (rows + 2) x (columns + 2)
+// input patch: it is loaded ONCE per 16-channel chunk (K order: channel chunk outer, taps inner), activated once, and every tap's
+// A fragment is that LDS image at a wave-uniform offset.  Against the tap-major loop above that is 9x fewer activation loads,
+// ds_writes, LeakyReLUs and per-row address updates per K step - the instructions that wait for gaps between the other waves'
+// MFMAs - and the halo rows are fetched once per workgroup instead of once per tap
+// (tools/micro/igemm_lab.hip, profiles/r03_k_patch_resident_lab.txt: +6-8 % on 32x32 64->128, +20 % on 16x16 128->256, 0.92 of
+// the MFMA peak at K = 4608).  Only the weight tile is staged per K step.
+// Host guarantees: plain geometry (stride 1, no upsample, no parity classes), 3x3 taps, Ca % 16 == 0, H * W >= BM (a tile never
+// crosses an image), vector weight loads, split-K in whole chunks (kper = chunks per slice * 9).
+// -------------------------------------------------------------------------------------------------
+template <int BM, int BN, int TM, int TN, int BMODE>
+__global__ __launch_bounds__(256, TM * TN <= 2 ? 3 : 2) void conv_igemm_patch_kernel(const ConvP p) {
+    constexpr int KB = 16, LDK = KB + 4;
+    constexpr int WAVES_N = BN / (32 * TN), WAVES_M = BM / (32 * TM);
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int P_PER = BM == 64 ? 4 : 5;          // patch quads per thread: (BM / W + 2) * (min(W, BM) + 2) pixels <= 198 (BM 64) / 264 (BM 128, W <= 64)
+    constexpr int B_ROWS = BN / 64;                  // BMODE 0: weight rows per thread
+    constexpr int B_U = BN / 4, B_RSTEP = 256 / B_U; // BMODE 1: float4 units per k-row, k-rows per pass
+    constexpr int B_PER4 = (KB + B_RSTEP - 1) / B_RSTEP;
+    constexpr int B_SZ = (BMODE == 0) ? BN * LDK : KB * BN;
+    extern __shared__ __attribute__((aligned(16))) float patch_lds[];
+    const Geo& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int kslice = blockIdx.z;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // patch geometry (workgroup-uniform)
+    const int Wt = min(g.W, BM), logWt = 31 - __builtin_clz(Wt);
+    const int PW = Wt + 2, PP = (BM / Wt + 2) * PW;
+    const int P_SZ = (PP * LDK + 3) & ~3;
+    float* Ps = patch_lds;
+    float* Bs = patch_lds + 2 * P_SZ;
+    const int n_img = m0 >> (g.logH + g.logW);
+    const int oy0 = ((m0 >> g.logW) & (g.H - 1)) + g.off_y, ox0 = (m0 & (g.W - 1)) + g.off_x;
+    const int KF2 = g.KF * g.KFw;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xFFFFFFFFu, 0x00020000);
+    unsigned p_voff[P_PER];
+    int p_lds[P_PER];
+#pragma unroll
+    for (int i = 0; i < P_PER; ++i) {
+        const int q = t + 256 * i, pp = q >> 2, quad = q & 3;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int iy = oy0 + pr, ix = ox0 + pc;
+        const bool v = pp < PP && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        p_voff[i] = v ? (unsigned)((((n_img * g.Hin + iy) * g.Win + ix) * p.Ca + quad * 4) * 4) : BUF_OOB;
+        p_lds[i] = pp < PP ? pp * LDK + quad * 4 : -1;
+    }
+    unsigned b_voff[BMODE == 0 ? B_ROWS : B_PER4];
+    const int brow = t >> 2, bq = (t & 3) * 4;                 // BMODE 0
+    const int b4_krow = t / B_U, b4_col = (t % B_U) * 4;       // BMODE 1
+    if constexpr (BMODE == 0) {
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) b_voff[i] = (unsigned)((min(n0 + brow + 64 * i, p.Cb - 1) * KF2 * p.Cin_w + bq) * 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < B_PER4; ++i)
+            b_voff[i] = (unsigned)((min(b4_krow + i * B_RSTEP, KB - 1) * KF2 * p.Cin_w + min(n0 + b4_col, p.Cb - 4)) * 4);
+    }
+    const bool has_act = p.pre_slope != 1.0f;
+    f32x4 rp[P_PER], rb[BMODE == 0 ? B_ROWS : B_PER4];
+    auto load_patch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < P_PER; ++i) rp[i] = buf_load4(rx, p_voff[i], (unsigned)(c0 * 4));
+    };
+    int p_wr = 0;   // float offset of the patch buffer the next store_patch fills (alternates 0 / P_SZ)
+    auto store_patch = [&](int) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < P_PER; ++i) {
+            if (has_act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rp[i][e] = __builtin_amdgcn_fmed3f(rp[i][e], rp[i][e] * p.pre_slope, p.pos_inf);
+            }
+            if (p_lds[i] >= 0) *reinterpret_cast<f32x4*>(&Ps[p_wr + p_lds[i]]) = rp[i];
+        }
+        p_wr = p_wr ? 0 : P_SZ;
+    };
+    auto load_b = [&](int ta, int tb, int c0) __attribute__((always_inline)) {
+        const int wtap = (g.wa_base + g.wa_step * ta) * g.KFw + g.wb_base + g.wb_step * tb;
+        if constexpr (BMODE == 0) {
+            const unsigned sb = (unsigned)((wtap * p.Cin_w + c0) * 4);
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_voff[i], sb);
+        } else {
+            const unsigned sb = (unsigned)(((c0 * KF2 + wtap) * p.Cin_w) * 4);
+#pragma unroll
+            for (int i = 0; i < B_PER4; ++i) rb[i] = buf_load4(rw, b_voff[i], sb);
+        }
+    };
+    auto store_b = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (BMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + (brow + 64 * i) * LDK + bq]) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_PER4; ++i) {
+                const int krow = b4_krow + i * B_RSTEP;
+                if (krow < KB) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + krow * BN + b4_col]) = rb[i];
+            }
+        }
+    };
+    const int r = lane & 31, h = lane >> 5;
+    const int wm0 = (wv / WAVES_N) * 32 * TM, wn0 = (wv % WAVES_N) * 32 * TN;
+    // lane constants of the A fragment: tile-local pixel (ty, tx) of row wm0 + 32 i + r sits at patch position (ty + ta) * PW + tx + tb
+    // for tap (ta, tb): one base per tap ROW (the patch buffer of the current chunk folded in), tb and the k quad are immediates
+    int a_row[3][TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int q = wm0 + 32 * i + r;
+        const int base = ((q >> logWt) * PW + (q & (Wt - 1))) * LDK + 4 * h;
+#pragma unroll
+        for (int ta = 0; ta < 3; ++ta) a_row[ta][i] = base + ta * PW * LDK;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // split-K in whole chunks: kper = chunks per slice * 9
+    const int nchunk = p.Ca / KB;
+    const int ch0 = kslice * (p.kper / 9);
+    const int ch1 = min(nchunk, ch0 + p.kper / 9);
+    load_patch(ch0 * KB);
+    load_b(0, 0, ch0 * KB);
+    store_patch(0);
+    store_b(0);
+    __syncthreads();
+    // one K step: tap TAP of chunk ch (weight buffer BB: compile-time, the patch buffer is folded into a_row); prefetches the next
+    // step's weights and - on the first tap - the next chunk's patch, which goes to LDS behind the last tap's MFMAs
+    auto kstep = [&](int ch, bool more_chunks, auto TAPC, auto BBC) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(TAPC)::value, BB = decltype(BBC)::value;
+        constexpr int TA = TAP / 3, TB = TAP % 3;
+        if (TAP == 0 && more_chunks) load_patch((ch + 1) * KB);
+        if (TAP < 8) load_b((TAP + 1) / 3, (TAP + 1) % 3, ch * KB);
+        else if (more_chunks) load_b(0, 0, (ch + 1) * KB);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Bb = Bs + BB * B_SZ;
+        f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[kk][i] = *reinterpret_cast<const f32x4*>(&Ps[a_row[TA][i] + TB * LDK + 8 * kk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (BMODE == 0) {
+                    b[kk][j] = *reinterpret_cast<const f32x4*>(&Bb[(wn0 + 32 * j + r) * LDK + 8 * kk + 4 * h]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[kk][j][e] = Bb[(8 * kk + 4 * h + e) * BN + wn0 + 32 * j + r];
+                }
+            }
+        }
+        if constexpr (TM * TN <= 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i][e], b[kk][j][e], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (TAP < 8 || more_chunks) store_b(BB ^ 1);
+        if (TAP == 8 && more_chunks) store_patch(-1);
+        __syncthreads();
+    };
+    int pbuf = 0;   // patch buffer of the chunk being computed
+    auto chunk = [&](int ch, auto B0C) __attribute__((always_inline)) {   // nine taps; the weight buffer alternates, starting at B0
+        constexpr int B0 = decltype(B0C)::value;
+        using Ba = std::integral_constant<int, B0>;
+        using Bb_ = std::integral_constant<int, B0 ^ 1>;
+        const bool more_chunks = ch + 1 < ch1;
+        kstep(ch, more_chunks, std::integral_constant<int, 0>(), Ba());
+        kstep(ch, more_chunks, std::integral_constant<int, 1>(), Bb_());
+        kstep(ch, more_chunks, std::integral_constant<int, 2>(), Ba());
+        kstep(ch, more_chunks, std::integral_constant<int, 3>(), Bb_());
+        kstep(ch, more_chunks, std::integral_constant<int, 4>(), Ba());
+        kstep(ch, more_chunks, std::integral_constant<int, 5>(), Bb_());
+        kstep(ch, more_chunks, std::integral_constant<int, 6>(), Ba());
+        kstep(ch, more_chunks, std::integral_constant<int, 7>(), Bb_());
+        kstep(ch, more_chunks, std::integral_constant<int, 8>(), Ba());
+        // the next chunk's patch is in the other buffer: move the A bases there
+        const int d = pbuf ? -P_SZ : P_SZ;
+        pbuf ^= 1;
+#pragma unroll
+        for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a_row[ta][i] += d;
+    };
+    int ch = ch0;
+    for (; ch + 1 < ch1; ch += 2) {   // pairs: after nine steps the weight buffer parity has flipped
+        chunk(ch, std::integral_constant<int, 0>());
+        chunk(ch + 1, std::integral_constant<int, 1>());
+    }
+    if (ch < ch1) chunk(ch, std::integral_constant<int, 0>());
+
+    // ---- epilogue (as conv_igemm_kernel) ----
+    EpiCtx ec;
+    ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
+    ec.mask_slope = p.mask_slope;
+    ec.post_slope = p.post_slope;
+    const bool first = kslice == 0;
+    const bool has_res = p.res != nullptr && first, has_mask = p.mask_x != nullptr;
+    ec.atom = p.ksplit > 1;
+    ec.remap = false;
+    ec.M = p.M; ec.Cb = p.Cb;
+    ec.logH = g.logH; ec.logW = g.logW; ec.Hm1 = g.H - 1; ec.Wm1 = g.W - 1; ec.os = 1; ec.py = 0; ec.px = 0;
+    ec.Ho = g.H; ec.Wo = g.W;
+    const unsigned ybytes = (unsigned)g.N * (unsigned)g.H * (unsigned)g.W * (unsigned)p.Cb * 4u;
+    ec.ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
+    ec.rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, has_res ? (p.res_ups ? ybytes >> 2 : ybytes) : 0u, 0x00020000);
+    ec.rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_x, 0, has_mask ? ybytes : 0u, 0x00020000);
+    auto run = [&](auto MODEC) {
+        constexpr int MODE = decltype(MODEC)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int co = n0 + wn0 + 32 * j + r;
+                const bool cok = co < p.Cb;
+                const float bv = (p.bias && first && cok) ? p.bias[co] : 0.f;
+                float a[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a[e] = acc[i][j][e];
+                epi_block<16, MODE>(ec, a, m0 + wm0 + 32 * i + 4 * h, co, cok, bv);
+            }
+    };
+    if (has_res) {
+        if (p.res_ups) run(std::integral_constant<int, 2>());
+        else run(std::integral_constant<int, 1>());
+    } else if (has_mask) {
+        run(std::integral_constant<int, 3>());
+    } else {
+        run(std::integral_constant<int, 0>());
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // wgrad
 // -------------------------------------------------------------------------------------------------
 struct WgP {
@@ -1219,6 +1461,66 @@ static void launch_64x64(const ConvP& p, size_t y_elems, hipStream_t st, bool ta
     launch_cfg<64, 64, 1, 1, BMODE, GEN>(p, y_elems, st, table_hit);
 }
 
+// Patch-resident launch (conv_igemm_patch_kernel) of a plain 3x3 convolution on the fast path, when the geometry allows it; the
+// tile and split-K choice are the caller's / the table row's (tile code + 20000) / the heuristic's.  Returns false when the launch
+// is not eligible (the tap-major kernel runs).  tools/patch_autotune.py compares the two kernels per layer.
+template <int BM, int BN, int TM, int TN, int BMODE>
+static void launch_patch_cfg(ConvP p, size_t y_elems, hipStream_t st, bool table_hit) {
+    const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
+    const int chunks = p.Ca / 16, T = 9;
+    int ks = plan_ksplit((long long)gx * gy, chunks * T, BM * BN, p.tune_ks);
+    if (ks > chunks) ks = chunks;
+    const int cps = (chunks + ks - 1) / ks;
+    p.ksplit = (chunks + cps - 1) / cps;
+    p.kper = cps * T;
+    if (t_plan_out) {
+        const int32_t v[8] = {table_hit ? 1 : 0, BM, BN, p.ksplit, gx, gy, p.ksplit, 1};
+        for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
+        return;
+    }
+    if (p.ksplit > 1 && p.post_slope != 1.f) {
+        gim_set_error("conv fwd: post_slope with a launch that splits K (ask gim_conv_launch_plan first)");
+        t_launch_refused = true;
+        return;
+    }
+    if (p.ksplit > 1 && !p.y_zeroed) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
+    const int Wt = p.g.W < BM ? p.g.W : BM;
+    const int PP = (BM / Wt + 2) * (Wt + 2);
+    const int P_SZ = (PP * 20 + 3) & ~3;
+    const int B_SZ = (BMODE == 0) ? BN * 20 : 16 * BN;
+    const size_t lds = (size_t)(2 * P_SZ + 2 * B_SZ) * sizeof(float);
+    hipLaunchKernelGGL((conv_igemm_patch_kernel<BM, BN, TM, TN, BMODE>), dim3(gx, gy, p.ksplit), dim3(256), lds, st, p);
+}
+
+template <int BMODE>
+static bool launch_patch(const ConvP& p, size_t y_elems, hipStream_t st, int want, bool table_hit) {
+    const Geo& g = p.g;
+    if (g.pc || g.ups || g.s_in != 1 || g.s_in_x != 1 || g.os != 1 || g.Th != 3 || g.Tw != 3) return false;
+    if (p.Ca % 16 != 0 || p.Cb < 32 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return false;
+    if (BMODE == 1 && p.Cb % 4 != 0) return false;
+    const int HW = g.H * g.W;
+    if (HW < 64) return false;
+    // tile: the caller's / table's choice, else as launch_igemm's heuristic; 128-row tiles need H * W >= 128 and W <= 64
+    int cfg = want;
+    if (cfg == 6432) cfg = 64;
+    if (cfg != 128 && cfg != 641 && cfg != 1264 && cfg != 64) {
+        if (p.Cb > 64) {
+            const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cb + 127) / 128);
+            cfg = p.M <= 64 ? 641 : (t128 < GIM_SMALL_TILES ? 64 : 641);
+        } else {
+            cfg = p.M <= 64 ? 64 : 1264;
+        }
+    }
+    if (p.Cb <= 64 && (cfg == 128 || cfg == 641)) cfg = cfg == 128 ? 1264 : 64;
+    if ((cfg == 128 || cfg == 1264) && (HW < 128 || g.W > 64)) cfg = cfg == 128 ? 641 : 64;
+    if (p.Cb <= 64 && cfg == 641) cfg = 64;
+    if (cfg == 128) launch_patch_cfg<128, 128, 2, 2, BMODE>(p, y_elems, st, table_hit);
+    else if (cfg == 641) launch_patch_cfg<64, 128, 1, 2, BMODE>(p, y_elems, st, table_hit);
+    else if (cfg == 1264) launch_patch_cfg<128, 64, 2, 1, BMODE>(p, y_elems, st, table_hit);
+    else launch_patch_cfg<64, 64, 1, 1, BMODE>(p, y_elems, st, table_hit);
+    return true;
+}
+
 // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K.
 // tune_tile / tune_ks: the caller's explicit choice (gim_conv_shape.tune_tile / tune_ksplit; tune_tile < 0 = heuristics only),
 // else the table row of this shape, else the heuristic.
@@ -1230,7 +1532,14 @@ static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     const TuneEntry* te = forced ? nullptr : tune_lookup(p.tune_kind, M, p.Ca, Cb, p.Ktot, p.g.pc);
     if (te) pt.tune_ks = te->ks;
     const bool hit = te != nullptr;
-    const int want = p.tune_tile > 0 ? p.tune_tile : (te ? te->tile : 0);   // 0: heuristic
+    int want = p.tune_tile > 0 ? p.tune_tile : (te ? te->tile : 0);   // 0: heuristic
+    // tile code + 20000: the patch-resident kernel (plain 3x3 layers); rows and caller choices without it keep the tap-major loop
+    // they were tuned on; a launch with neither row nor caller choice takes the patch-resident kernel where the geometry allows it
+    const bool patch_row = want >= 20000;
+    if (patch_row) want -= 20000;
+    if constexpr (GEN == 0) {
+        if ((patch_row || (!te && p.tune_tile == 0 && p.tune_ks == 0)) && launch_patch<BMODE>(pt, y_elems, st, want, hit)) return;
+    }
     if (Cb > 64) {
         const long long t128 = (long long)((M + 127) / 128) * ((Cb + 127) / 128) * (p.g.pc ? 4 : 1);
         int cfg = want ? want : (M <= 64 ? 641 : (t128 < GIM_SMALL_TILES ? 64 : 641));

@@ -251,6 +251,174 @@ __global__ __launch_bounds__(256, lab_lds_bytes(BM, BN, KB, VAR) <= 40960 ? 4 : 
     }
 }
 
+// VAR 2: input patch resident in LDS.  The 3 x 3 taps of a tile of BM consecutive output rows read the BM + 2 * WIMG + 2 input rows
+// m0 .. m0 + BM + 2 * WIMG + 1: they are loaded ONCE per 16-channel chunk (K order: channel chunk outer, taps inner) and every tap's
+// A fragment is the same LDS image at a compile-time row offset (ds_read immediate) - 9x fewer activation loads, ds_writes,
+// activations and address updates per K step; only the weight tile is staged per step.
+template <int BM, int BN, int TM, int TN, int WIMG>
+__global__ __launch_bounds__(256, 3) void lab_patch_kernel(const LabP p) {
+    constexpr int KB = 16, LDK = KB + 4;
+    constexpr int WAVES_N = BN / (32 * TN), WAVES_M = BM / (32 * TM);
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int PR = BM + 2 * WIMG + 2;             // patch rows
+    constexpr int PQ = PR * 4;                        // 16-byte quads per patch
+    constexpr int P_PER = (PQ + 255) / 256;           // quads per thread
+    constexpr int B_ROWS = BN / 64;                   // weight rows per thread (64 rows per pass: 4 quads per row)
+    constexpr int P_SZ = PR * LDK, B_SZ = BN * LDK;
+    __shared__ __attribute__((aligned(16))) float lds[2 * P_SZ + 2 * B_SZ];
+    float* Ps = lds;
+    float* Bs = lds + 2 * P_SZ;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int K = p.T * p.Ca;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xFFFFFFFFu, 0x00020000);
+    unsigned p_voff[P_PER];
+    int p_lds[P_PER];
+#pragma unroll
+    for (int i = 0; i < P_PER; ++i) {
+        const int q = t + 256 * i, row = q >> 2, quad = q & 3;
+        p_voff[i] = q < PQ ? (unsigned)(((m0 + row) * p.Ca + quad * 4) * 4) : BUF_OOB;
+        p_lds[i] = (q < PQ ? row : 0) * LDK + quad * 4;
+    }
+    const int brow = t >> 2, bq = (t & 3) * 4;
+    unsigned b_voff[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) b_voff[i] = (unsigned)((min(n0 + brow + 64 * i, p.N - 1) * K + bq) * 4);
+    const bool has_act = p.slope != 1.0f;
+    f32x4 rp[P_PER], rb[B_ROWS];
+    auto load_patch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < P_PER; ++i) rp[i] = buf_load4(rx, p_voff[i], (unsigned)(c0 * 4));
+    };
+    auto store_patch = [&](int pb) {
+#pragma unroll
+        for (int i = 0; i < P_PER; ++i) {
+            if (has_act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rp[i][e] = __builtin_amdgcn_fmed3f(rp[i][e], rp[i][e] * p.slope, p.pos_inf);
+            }
+            if (P_PER * 256 == PQ || t + 256 * i < PQ) *reinterpret_cast<f32x4*>(&Ps[pb * P_SZ + p_lds[i]]) = rp[i];
+        }
+    };
+    auto load_b = [&](int tap, int c0) {
+        const unsigned sb = (unsigned)((tap * p.Ca + c0) * 4);
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_voff[i], sb);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + (brow + 64 * i) * LDK + bq]) = rb[i];
+    };
+    const int r = lane & 31, h = lane >> 5;
+    const int wm0 = (wv / WAVES_N) * 32 * TM, wn0 = (wv % WAVES_N) * 32 * TN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nchunk = p.Ca / KB;
+    load_patch(0);
+    load_b(0, 0);
+    store_patch(0);
+    store_b(0);
+    __syncthreads();
+    // one K step: tap TAP of chunk `ch` (patch buffer PB, weight buffer BB); prefetches the next step's weights, and - on the
+    // first tap - the next chunk's patch, which is written to LDS behind the last tap's MFMAs
+    auto kstep = [&](int ch, auto TAPC, auto PBC, auto BBC) {
+        constexpr int TAP = decltype(TAPC)::value, PB = decltype(PBC)::value, BB = decltype(BBC)::value;
+        const bool more_chunks = ch + 1 < nchunk;
+        if (TAP == 0 && more_chunks) load_patch((ch + 1) * KB);
+        if (TAP < 8) load_b(TAP + 1, ch * KB);
+        else if (more_chunks) load_b(0, (ch + 1) * KB);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int TOFF = ((TAP / 3) * WIMG + (TAP % 3)) * LDK;
+        const float* Ab = Ps + PB * P_SZ + TOFF;
+        const float* Bb = Bs + BB * B_SZ;
+        f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[kk][i] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + 32 * i + r) * LDK + 8 * kk + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[kk][j] = *reinterpret_cast<const f32x4*>(&Bb[(wn0 + 32 * j + r) * LDK + 8 * kk + 4 * h]);
+        }
+        if constexpr (TM * TN <= 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i][e], b[kk][j][e], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (TAP < 8 || more_chunks) store_b(BB ^ 1);
+        if (TAP == 8 && more_chunks) store_patch(PB ^ 1);
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto chunk = [&](int ch, auto PBC, auto B0C) {   // nine taps; the weight buffer alternates, starting at B0
+        constexpr int B0 = decltype(B0C)::value;
+        using Ba = std::integral_constant<int, B0>;
+        using Bb_ = std::integral_constant<int, B0 ^ 1>;
+        kstep(ch, std::integral_constant<int, 0>(), PBC, Ba());
+        kstep(ch, std::integral_constant<int, 1>(), PBC, Bb_());
+        kstep(ch, std::integral_constant<int, 2>(), PBC, Ba());
+        kstep(ch, std::integral_constant<int, 3>(), PBC, Bb_());
+        kstep(ch, std::integral_constant<int, 4>(), PBC, Ba());
+        kstep(ch, std::integral_constant<int, 5>(), PBC, Bb_());
+        kstep(ch, std::integral_constant<int, 6>(), PBC, Ba());
+        kstep(ch, std::integral_constant<int, 7>(), PBC, Bb_());
+        kstep(ch, std::integral_constant<int, 8>(), PBC, Ba());
+    };
+    int ch = 0;
+    for (; ch + 1 < nchunk; ch += 2) {   // pairs: after nine steps the weight buffer parity has flipped
+        chunk(ch, I0(), I0());
+        chunk(ch + 1, I1(), I1());
+    }
+    if (ch < nchunk) chunk(ch, I0(), I0());
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn0 + 32 * j + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < p.M && col < p.N) p.y[(long long)row * p.N + col] = acc[i][j][e];
+            }
+        }
+}
+
+template <int BM, int BN, int TM, int TN, int WIMG>
+static void run_patch(LabP p, const std::vector<double>& ref, int ref_rows) {
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
+    CK(hipMemset(p.y, 0xFF, (size_t)p.M * p.N * 4));
+    hipLaunchKernelGGL((lab_patch_kernel<BM, BN, TM, TN, WIMG>), grid, dim3(256), 0, 0, p);
+    CK(hipDeviceSynchronize());
+    std::vector<float> y((size_t)ref_rows * p.N);
+    CK(hipMemcpy(y.data(), p.y, y.size() * 4, hipMemcpyDeviceToHost));
+    double emax = 0, rmax = 0;
+    for (size_t i = 0; i < y.size(); ++i) { emax = fmax(emax, fabs((double)y[i] - ref[i])); rmax = fmax(rmax, fabs(ref[i])); }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 20;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((lab_patch_kernel<BM, BN, TM, TN, WIMG>), grid, dim3(256), 0, 0, p);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((lab_patch_kernel<BM, BN, TM, TN, WIMG>), grid, dim3(256), 0, 0, p);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s %4dx%-3d KB16  %8.4f ms %7.1f TF  err %.1e\n", "LDS-resident patch (chunk-major K)", BM, BN, ms / reps,
+           2.0 * p.M * p.N * (double)p.T * p.Ca / (ms / reps) / 1e9, emax / rmax);
+}
+
 // naive reference for rows [0, rows): double accumulation
 __global__ void ref_kernel(const LabP p, int rows, double* out) {
     const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,8 +516,8 @@ int main(int argc, char** argv) {
         double* dref;
         CK(hipMalloc(&dref, (size_t)ref_rows * s.N * 8));
         printf("== %s: M=%d N=%d K=%d (%.2f GFLOP)\n", s.what, s.M, s.N, s.T * s.Ca, 2.0 * s.M * s.N * s.T * s.Ca / 1e9);
-        for (int pass = 0; pass < 2; ++pass) {
-            p.slope = pass == 0 ? 0.2f : 1.0f;
+        for (int pass = 0; pass < 3; ++pass) {
+            p.slope = pass == 1 ? 1.0f : 0.2f;
             p.oob_test = pass == 0 ? 1 : 0;
             p.prio = 0;
             hipLaunchKernelGGL(ref_kernel, dim3((ref_rows * s.N + 255) / 256), dim3(256), 0, 0, p, ref_rows, dref);
@@ -360,8 +528,21 @@ int main(int argc, char** argv) {
                 run<64, 64, 1, 1, 32, 0, false>(p, "staged", ref, ref_rows);
                 if (s.N >= 128) run<64, 128, 1, 2, 16, 0, false>(p, "staged", ref, ref_rows);
                 run<128, 64, 2, 1, 16, 0, false>(p, "staged", ref, ref_rows);
-                run<64, 64, 1, 1, 32, 0, true>(p, "staged, STAMPED", ref, ref_rows);
-                if (s.N >= 128) run<64, 128, 1, 2, 16, 0, true>(p, "staged, STAMPED", ref, ref_rows);
+                if (round == 0) {
+                    run<64, 64, 1, 1, 32, 0, true>(p, "staged, STAMPED", ref, ref_rows);
+                    if (s.N >= 128) run<64, 128, 1, 2, 16, 0, true>(p, "staged, STAMPED", ref, ref_rows);
+                }
+                if (!p.oob_test && s.T == 9) {
+                    if (s.Wimg == 32) {
+                        run_patch<64, 64, 1, 1, 32>(p, ref, ref_rows);
+                        if (s.N >= 128) run_patch<64, 128, 1, 2, 32>(p, ref, ref_rows);
+                        run_patch<128, 64, 2, 1, 32>(p, ref, ref_rows);
+                    } else if (s.Wimg == 16) {
+                        run_patch<64, 64, 1, 1, 16>(p, ref, ref_rows);
+                        if (s.N >= 128) run_patch<64, 128, 1, 2, 16>(p, ref, ref_rows);
+                        run_patch<128, 64, 2, 1, 16>(p, ref, ref_rows);
+                    }
+                }
             }
         }
         CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy)); CK(hipFree(dref));
