@@ -13,7 +13,7 @@ print("shape: %d images %dx%d, %d -> %d channels, 3x3 (M = %d output pixels)" % 
 by = {}
 for r in rows:
     nm = r["Kernel_Name"]
-    if not nm.startswith(("void conv_igemm_kernel", "void conv_wgrad_kernel")):
+    if not nm.startswith(("void conv_igemm_kernel", "void conv_igemm_patch_kernel", "void conv_wgrad_kernel")):
         continue
     g = (int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
     by.setdefault((nm.split("(")[0].replace("void ", ""), g), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
