@@ -47,6 +47,9 @@ CONV_CASES = [
     (2, 128, 256, 3, 32, 0, 0.2, False, True),     # M=2048: 128-wide tiles
     (3, 32, 64, 3, 16, 1, 0.2, False, True),       # sub-pixel form, vector paths
     (2, 16, 16, 9, 8, 1, 1.0, True, False),        # sub-pixel 9x9 (5x5 taps per class)
+    (1, 16, 32, 3, 128, 0, 0.2, True, True),       # patch-resident loop, 128-wide map: a 64-pixel tile is half an image row
+    (5, 32, 48, 3, 8, 0, 0.2, False, True),        # patch-resident loop, 8x8 map: one tile = one image, ragged output channels
+    (3, 48, 96, 3, 4, 0, 0.2, True, True),         # 4x4 map: below the patch kernel's 64 pixels, tap-major loop
 ]
 
 POOL_CASES = [
