@@ -49,7 +49,9 @@ int gim_version(void);
  *   tune_tile / tune_ksplit / tune_wgrad : launch overrides for tools/conv_autotune.py and the tuned-row parity tests; 0
  *             (the product's value) = the table row of this shape, else the heuristic.  tune_tile: 128 = 128x128, 641 =
  *             64x128, 1264 = 128x64, 64 = 64x64 output tile, 6432 = 64x64 with a 32-deep K step (forward / dgrad: channel counts that
- *             are multiples of 32, wgrad: 32 pixels per step on the vector path; otherwise as 64), < 0 = ignore the table; tune_ksplit: split-K factor of
+ *             are multiples of 32, wgrad: 32 pixels per step on the vector path; otherwise as 64), tile code + 20000 (forward / dgrad of
+ *             plain 3x3 layers, forward of pool-folded 3x3 layers) = the patch-resident K loop on that tile (the input patch of a tile
+ *             stays in LDS for all taps; where the geometry does not allow it the tap-major loop runs), < 0 = ignore the table; tune_ksplit: split-K factor of
  *             fwd / dgrad; tune_wgrad: workgroup target of the wgrad pixel slicing.  Results never depend on them beyond
  *             the summation order.
  *   out_zeroed = 1: (gim_conv2d_fwd / _dgrad / _dgrad_t) the caller guarantees that the output buffer holds zeros.  Launches that
