@@ -1394,6 +1394,140 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgP p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Row-resident weight gradient of plain 3x3 convolutions: dW[co][ta][tb][ci] = sum_pixels dY[p][co] * act(x)[p + (ta, tb)][ci].
+// A workgroup owns 128 output channels x ONE tap row (ta; its three taps tb) x 32 input channels (wave w: channels 32 w .. 32 w + 31,
+// three 32 x 32 accumulator blocks) and walks its pixel slice 16 pixels at a time: the three taps read the same (columns + 2)-wide
+// rows of x, loaded once per step (18 pixels instead of 3 x 16) and activated once; every tap's B fragment is that LDS image at an
+// immediate offset, and the dY tile is read once for three taps.  24 MFMAs behind 32 scalar LDS reads per wave and step, 10 KB
+// staged per 16 pixels: 38 FLOP per staged byte against 16 for the column-tile kernel above.  (All nine taps per workgroup - 144
+// accumulator registers per lane, one or two waves per SIMD - was measured and is slower: profiles/r03_o_*.)
+// WT = min(W, 16): a step is 16 / WT image rows of WT pixels.
+// Host guarantees: plain geometry, 3x3, Cin % 32 == 0, Cout % 128 == 0, H * W >= 16, slices of whole steps, atomic combine.
+// -------------------------------------------------------------------------------------------------
+template <int WT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_row_kernel(const WgP p) {
+    constexpr int BMC = 128, CI = 32, PXS = 16, TRS = PXS / WT, PW = WT + 2, PP = TRS * PW;
+    constexpr int P_SZ = PP * CI, A_SZ = PXS * BMC;
+    static_assert(PP * 8 <= 256, "one patch quad per thread");
+    __shared__ __attribute__((aligned(16))) float Ps[2][P_SZ];
+    __shared__ __attribute__((aligned(16))) float As[2][A_SZ];
+    const Geo& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, h = lane >> 5;
+    const int ta = blockIdx.x % 3, ci0 = (blockIdx.x / 3) * CI, co0 = blockIdx.y * BMC;
+    const int mbeg = blockIdx.z * p.mper, mend = min(p.M, mbeg + p.mper);
+    // ---- x rows: 8 quads per pixel; lane constant relative to (row + ta - 1, column - 1) of the step's first pixel ----
+    const int b_bias = (g.Win + 1) * p.Cin * 4;   // shifted into the base pointer: every offset stays >= 0
+    const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - b_bias), 0, p.x_bytes + (unsigned)b_bias, 0x00020000);
+    const int pp = t >> 3, quad = t & 7;
+    const int pr = pp / PW, pc = pp - pr * PW;
+    const int p_dy = pr + ta - 1, p_dx = pc - 1;
+    const unsigned p_l = (unsigned)((((pr + ta) * g.Win + pc) * p.Cin + ci0 + quad * 4) * 4);
+    const int p_lds = pp < PP ? pp * CI + quad * 4 : -1;
+    // ---- dY rows: 32 quads per pixel row (128 channels) ----
+    const int a_row = t >> 5, a_cq = (t & 31) * 4;
+    unsigned a_v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_v[i] = (unsigned)(((a_row + 8 * i) * p.Cout + co0 + a_cq) * 4);
+    const bool do_bias = p.bias_slabs != nullptr && blockIdx.x == 0;   // block-uniform
+    const bool act_b = p.pre_slope != 1.0f;
+    f32x4 ra[2], rp;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_tiles = [&](int mb) __attribute__((always_inline)) {
+        const int left = mend - mb;
+        const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.dy + (long long)mb * p.Cout), 0, (unsigned)min(left, PXS) * (unsigned)p.Cout * 4u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = buf_load4(ra_rs, a_v[i], 0);
+        const int n = mb >> (g.logH + g.logW);
+        const int oy = (mb >> g.logW) & (g.H - 1), ox = mb & (g.W - 1);
+        const unsigned u = (unsigned)((((n * g.Hin + oy) * g.Win) + ox) * p.Cin * 4);
+        const bool v = p_lds >= 0 && (unsigned)(oy + p_dy) < (unsigned)g.Hin && (unsigned)(ox + p_dx) < (unsigned)g.Win;
+        rp = buf_load4(rxb, v ? p_l : BUF_OOB, u);
+    };
+    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+        if (do_bias) {
+            asm volatile("" ::: "memory");   // a real branch (see conv_wgrad_kernel)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[e] += ra[i][e];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&As[buf][(a_row + 8 * i) * BMC + a_cq]) = ra[i];
+        if (act_b) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rp[e] = __builtin_amdgcn_fmed3f(rp[e], rp[e] * p.pre_slope, p.pos_inf);
+        }
+        if (p_lds >= 0) *reinterpret_cast<f32x4*>(&Ps[buf][p_lds]) = rp;
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tb][e] = 0.f;
+    const int nk = (mend > mbeg) ? (mend - mbeg + PXS - 1) / PXS : 0;
+    if (nk > 0) {
+        load_tiles(mbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const float* a_rd = &As[0][0] + h * BMC + wv * 32 + r;
+    const float* b_rd = &Ps[0][0] + h * CI + r;
+    auto kstep = [&](int ks, auto BUFC, auto MAINC) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUFC)::value;
+        constexpr bool MAIN = decltype(MAINC)::value;
+        if (MAIN || ks + 1 < nk) load_tiles(mbeg + (ks + 1) * PXS);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kp = 0; kp < PXS / 2; ++kp) {
+            const float a = a_rd[buf * A_SZ + 2 * kp * BMC];
+            constexpr int dummy = 0; (void)dummy;
+            const int pos = ((2 * kp) / WT) * PW + (2 * kp) % WT;   // patch position of pixel 2 kp for tap column 0; pixel 2 kp + 1 is the next one
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb) {
+                const float b = b_rd[buf * P_SZ + (pos + tb) * CI];
+                acc[tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tb], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MAIN || ks + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    };
+    int ks = 0;
+    for (; ks + 2 < nk; ks += 2) {
+        kstep(ks, std::integral_constant<int, 0>(), std::true_type());
+        kstep(ks + 1, std::integral_constant<int, 1>(), std::true_type());
+    }
+    for (; ks + 1 < nk; ks += 2) {
+        kstep(ks, std::integral_constant<int, 0>(), std::false_type());
+        kstep(ks + 1, std::integral_constant<int, 1>(), std::false_type());
+    }
+    if (ks < nk) kstep(ks, std::integral_constant<int, 0>(), std::false_type());
+    // out[co][ta][tb][ci]: each accumulator register is two 128-byte row segments per wave
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) {
+        const int col = (ta * 3 + tb) * p.Cin + ci0 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            atomicAdd(&p.slabs[(long long)co * p.Kcols + col], acc[tb][e]);
+        }
+    }
+    if (do_bias) {   // As is free after the loop's last barrier
+        float* red = &As[0][0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[a_row * BMC + a_cq + e] = bsum[e];
+        __syncthreads();
+        if (t < BMC) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) sacc += red[rr * BMC + t];
+            atomicAdd(&p.bias_slabs[co0 + t], sacc);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // folded weights: F[co][a][b][ci] = sum_{dh,dw in {0,1}} W[co][a-dh][b-dw][ci],  a, b in [0, K]
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fold_weights_kernel(const float* __restrict__ w, float* __restrict__ f, int Cout, int Cin, int K) {
@@ -1950,7 +2084,7 @@ extern "C" int gim_conv2d_dgrad_xfold(const float* dy, const float* wx, const fl
 // stride 2 over the (K+1)^2 folded taps -> slabs in F layout [Cout][KF][KF][Cin].  sub-pixel (ups + wfold), roles
 // swapped: A = leaky_relu(x) [N,H/2,W/2,Cin], B = dy [N,H,W,Cout] gathered with stride 2 -> slabs
 // G[Cin][KF][KF][Cout] with G[ci][ta][tb][co] = dF[co][K-ta][K-tb][ci] (gim_wgrad_finish un-transposes).
-struct WgPlan { int bm, bn, ns, mper, rows, cols, M, table_hit, bk; };
+struct WgPlan { int bm, bn, ns, mper, rows, cols, M, table_hit, bk, patch, patch_target; };
 
 static WgPlan wgrad_plan(const gim_conv_shape* s) {
     WgPlan q{};
@@ -1968,6 +2102,7 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
         const TuneEntry* te = tune_lookup(2, (int)M, q.rows, q.cols, s->KH, pcw);
         if (te) { target = te->ks; tile = te->tile; q.table_hit = 1; }
     }
+    if (tile >= 20000) { q.patch = 1; q.patch_target = target; tile -= 20000; }   // row-resident kernel (plain 3x3 layers)
     q.bm = q.rows > 64 ? 128 : (q.rows > 32 ? 64 : 32);
     q.bn = (q.bm == 32) ? 128 : (q.cols > 64 ? 128 : 64);
     if (tile == 128) { q.bm = 128; q.bn = 128; }
@@ -2145,6 +2280,30 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     if (atomic && !prezeroed && !t_plan_out) {
         (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
         if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
+    }
+    // plain 3x3, row-resident kernel: on request (tile code >= 20000 from the caller or the table row; ks / target = workgroups wanted)
+    if (q.patch && atomic && s->KH == 3 && !s->wfold && !s->ups && !s->pool && s->Cin % 32 == 0 && s->Cout % 128 == 0 && s->H * s->W >= 16 &&
+        !((uintptr_t)dy & 15) && !((uintptr_t)x & 15)) {
+        const int tiles = 3 * (s->Cin / 32) * (s->Cout / 128);
+        long long S = ((q.patch_target > 0 ? q.patch_target : 1024) + tiles - 1) / tiles;
+        const long long maxS = (q.M + 127) / 128;          // at least 8 steps per slice
+        if (S > maxS) S = maxS;
+        if (S < 1) S = 1;
+        long long mp = (q.M + S - 1) / S;
+        mp = (mp + 15) / 16 * 16;
+        const int nsp = (int)((q.M + mp - 1) / mp);
+        if (t_plan_out) {
+            const int32_t v[8] = {q.table_hit, 128, 96, nsp, 3 * (s->Cin / 32), s->Cout / 128, nsp, 1};
+            for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
+            return GIM_OK;
+        }
+        p.mper = (int)mp; p.ns = nsp;
+        const dim3 gp(3 * (s->Cin / 32), s->Cout / 128, nsp);
+        const int Wt = s->W < 16 ? s->W : 16;
+        if (Wt == 16) hipLaunchKernelGGL(conv_wgrad_row_kernel<16>, gp, dim3(256), 0, (hipStream_t)stream, p);
+        else if (Wt == 8) hipLaunchKernelGGL(conv_wgrad_row_kernel<8>, gp, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(conv_wgrad_row_kernel<4>, gp, dim3(256), 0, (hipStream_t)stream, p);
+        return gim_check_launch("gim_conv2d_wgrad");
     }
     // 1x1 convolution with <= 8 channels on one side, atomic combine: the outer-product kernel (no table row: nothing to choose)
     if (s->KH == 1 && !s->wfold && !s->ups && !s->pool && atomic && (s->Cin <= 8 || s->Cout <= 8) && (s->Cin >= 16 || s->Cout >= 16) && q.M % NARROW_U == 0 &&

@@ -614,6 +614,38 @@ def test_dgrad_xfold_narrow_input(N, S, Cin, Cout, K, J, slope):
     assert relerr(nchw(dx), xr.grad) < TOL
 
 
+@pytest.mark.parametrize("N,S,Cin,Cout,slope,target", [(5, 32, 64, 128, 0.2, 0), (9, 8, 96, 256, 0.2, 64), (33, 4, 32, 128, 1.0, 0), (3, 64, 32, 128, 0.2, 700),
+                                                        (7, 16, 128, 384, 0.2, 0)])
+def test_wgrad_row_resident_3x3(N, S, Cin, Cout, slope, target):
+    """Weight + bias gradient of plain 3x3 convolutions on the ROW-RESIDENT kernel (tile code 20000: a workgroup owns 128 output
+    channels x one tap row x 32 input channels; the x rows of 16 pixels stay in LDS for the row's three taps) against fp64 autograd of
+    F.conv2d: maps of 4 ... 64 pixels per row (steps of four rows, two rows, one row, part of a row), slices that end inside an image,
+    the pre-activation on x, ADDING into what the arena slot holds."""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(31)
+    x = torch.randn(N, S, S, Cin, device=dev(), generator=g)
+    dy = torch.randn(N, S, S, Cout, device=dev(), generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    sh = _lib.GimConvShape(N, S, S, Cin, Cout, 3, 0, slope, 0, 0, 0, 20000, 0, target)
+    plan = (ctypes.c_int32 * 8)()
+    lib.gim_conv_launch_plan(sh, 3, ctypes.cast(plan, ctypes.c_void_p))
+    assert plan[7] == 1 and plan[4] == 3 * (Cin // 32) and plan[5] == Cout // 128, list(plan)
+    pre_w = torch.randn(Cout * 9 * Cin, device=dev(), generator=g)
+    pre_b = torch.randn(Cout, device=dev(), generator=g)
+    acc, bacc = pre_w.clone(), pre_b.clone()
+    _lib.check(lib.gim_conv2d_wgrad_acc(dy.data_ptr(), x.data_ptr(), acc.data_ptr(), bacc.data_ptr(), sh, st), "wgrad_acc")
+    xr = x.double().permute(0, 3, 1, 2)
+    wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device=dev(), requires_grad=True)
+    br = torch.zeros(Cout, dtype=torch.float64, device=dev(), requires_grad=True)
+    yr = F.conv2d(F.leaky_relu(xr, slope) if slope != 1.0 else xr, wr, br, padding=1)
+    (yr * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    got = (acc - pre_w).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    assert relerr(got.double(), wr.grad) < 1e-5
+    assert relerr((bacc - pre_b).double(), br.grad) < 1e-5
+
+
 def test_deterministic_wgrad_slabs_switch():
     """GIM_WGRAD_SLABS=1 (read at import: a child process): the non-queued weight-gradient path combines its pixel slices as slabs
     + a fixed-order reduce instead of float atomics - the parity cases still pass, and two runs of one weight gradient are bit-equal."""

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--workload", default="vox64")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--kinds", default="fwd,dgrad,pool,wgrad", help="fwd, dgrad (plain 3x3), pool (pool-folded forward), wgrad (plain 3x3)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     fwd, bwd = record_shapes(args.workload, args.batch)
@@ -32,7 +33,7 @@ def main():
     lines, tot_a, tot_b = [], 0.0, 0.0
     for cfg, cnt in sorted(fwd.items(), key=lambda kv: -kv[1]):
         N, H, W, Cin, Cout, KH, ups, slope, pool, fold = cfg
-        if KH == 3 and pool and fold and not ups and Cin % 16 == 0 and Cout >= 32 and (H // 2) * (W // 2) >= 64 and W // 2 <= 32:
+        if KH == 3 and pool and fold and not ups and Cin % 16 == 0 and Cout >= 32 and (H // 2) * (W // 2) >= 64 and W // 2 <= 32 and "pool" in args.kinds:
             # pool-folded forward: conv_igemm_patch_s2_kernel (64-row tiles)
             x = torch.randn(N, H, W, Cin, device=dev)
             f = torch.randn(Cout, 4, 4, Cin, device=dev) * 0.05
@@ -72,10 +73,32 @@ def main():
 
         def shape(tile=0, ks=0):
             return _lib.GimConvShape(N, H, W, Cin, Cout, 3, 0, slope, 0, 0, 0, tile, ks, 0)
+        n_dw = sum(c for (cf, dx_, dw), c in bwd.items() if cf == cfg and dw)
+        if n_dw and Cin % 32 == 0 and Cout % 128 == 0 and "wgrad" in args.kinds:   # row-resident weight gradient against the column-tile kernel
+            accw = torch.zeros(Cout * 9 * Cin, device=dev)
+
+            def wshape(tile=0, tg=0):
+                return _lib.GimConvShape(N, H, W, Cin, Cout, 3, 0, slope, 0, 0, 0, tile, 0, tg)
+            wfn = lambda s_: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), accw.data_ptr(), None, s_, st)   # noqa: E731
+            t_old = min(time_ms(lambda: wfn(wshape())) for _ in range(3))
+            bestw = (1e9, 0)
+            for tg in (256, 512, 768, 1024, 1536, 2048, 3072, 4096):
+                tw = time_ms(lambda: wfn(wshape(20000, tg)), reps=10)
+                if tw < bestw[0]:
+                    bestw = (tw, tg)
+            t_new = min(bestw[0], time_ms(lambda: wfn(wshape(20000, bestw[1]))))
+            usew = t_new < t_old * 0.98
+            tot_a += n_dw * t_old
+            tot_b += n_dw * (t_new if usew else t_old)
+            print("wgrad %-30s x%-2d column-tile kernel (table row) %.3f ms | row-resident best (target %d) %.3f ms  %+.1f %%"
+                  % (",".join(str(c) for c in cfg[:6]), n_dw, t_old, bestw[1], t_new, 100 * (t_old / t_new - 1)), flush=True)
+            if usew:
+                lines.append("    {2, %d, %d, %d, 3, 0, 20000, %d},  // wgrad %s: row-resident %.3f ms (column-tile kernel %.3f, row-resident %.3f)"
+                             % (N * H * W, Cout, 9 * Cin, bestw[1], ",".join(str(c) for c in cfg), t_new, t_old, t_new))
         runs = {"fwd": (cnt, 0, lambda s_: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), s_, st), Cout, (0, N * H * W, Cin, Cout, 9 * Cin, 0)),
                 "dgrad": (n_dx, 1, lambda s_: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), s_, st), Cin, (1, N * H * W, Cout, Cin, 9 * Cout, 0))}
         for kind, (calls, pk, fn, Cb, key) in runs.items():
-            if not calls:
+            if not calls or kind not in args.kinds:
                 continue
             plan = (ctypes.c_int32 * 8)()
             lib.gim_conv_launch_plan(shape(), pk, ctypes.cast(plan, ctypes.c_void_p))
