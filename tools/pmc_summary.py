@@ -16,7 +16,7 @@ for probe in sorted(os.listdir(os.path.join(root, "pmc"))):
     vals, kname = collections.defaultdict(list), None
     for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith(("void conv_igemm_kernel", "void conv_wgrad_kernel")):
+            if r["Kernel_Name"].startswith(("void conv_igemm_kernel", "void conv_igemm_patch", "void conv_wgrad_kernel", "void conv_wgrad_row_kernel")):
                 kname = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
     k = probe.split("_")

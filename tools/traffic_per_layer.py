@@ -12,7 +12,7 @@ def mean_kib(d):
     vals = []
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith(("void conv_igemm_kernel", "void conv_wgrad_kernel")):
+            if r["Kernel_Name"].startswith(("void conv_igemm_kernel", "void conv_igemm_patch", "void conv_wgrad_kernel", "void conv_wgrad_row_kernel")):
                 vals.append(float(r["Counter_Value"]))
     return sum(vals) / len(vals) if vals else float("nan")
 
