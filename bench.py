@@ -22,6 +22,10 @@ import gc
 import glob
 import json
 import os
+
+# one hardware queue per stream (the step's four + RCCL's): see optimalstrategiesagainstgenerativeattacks_amd/__init__.py;
+# set before anything touches the GPU, kept if the caller set it
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import shutil
 import socket
 import subprocess

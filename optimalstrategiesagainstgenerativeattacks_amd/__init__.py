@@ -6,6 +6,15 @@ Host-side mirror of the reference's Python API for that path (``get_au`` / ``get
 hand-written HIP kernels for gfx950 (``csrc/`` -> ``libgim_hip.so``, C ABI in ``include/gim_hip.h``).
 There is no CPU compute path: forward/backward/step need an MI355X and the built library.
 """
+import os as _os
+
+# The step runs on the caller's stream plus three streams of its own; RCCL adds its streams.  HIP deals streams onto hardware queues
+# round-robin (4 by default): when two of the step's streams land on one queue their kernels serialize and the step loses 6-12 %
+# (390 instead of 416 episodes/s; which streams collide depends on how many streams exist when they are created - a communicator
+# shifts it: profiles/r03_q_hw_queue_sweep.txt).  With 8 queues every stream has its own.  Read by the HIP runtime when it starts:
+# effective when this package is imported before the first GPU call; a value set by the user is kept.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .gim_img_models import (AdaInImage2Image, Encoder, EnvDecoder, GIMFaceAuthenticator, GIMFaceDis,
                              GIMFaceImpersonator, get_au, get_im)
 from .gim_gaussian_trainer import GIMGaussianTrainer
