@@ -26,17 +26,12 @@ import os
 # one hardware queue per stream (the step's four + RCCL's): see optimalstrategiesagainstgenerativeattacks_amd/__init__.py;
 # set before anything touches the GPU, kept if the caller set it
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-import shutil
-import socket
-import subprocess
-import sys
-import tempfile
-import time
-
-# Eight HIP hardware queues instead of the default four (read by the HIP runtime when it initialises): the engine's four
-# streams, torch's copy streams and RCCL's then sit on queues of their own instead of aliasing by creation order
-# (optimalstrategiesagainstgenerativeattacks_amd/gim_img_models.py, role -> stream map; profiles/r01_k_stream_map.txt)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import shutil  # noqa: E402
+import socket  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import tempfile  # noqa: E402
+import time  # noqa: E402
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -220,12 +215,12 @@ def dominant_kernel_roofline(per, device):
 
 
 def cpu_baseline(workload, m, n, k, sample_B):
-    """The oracle (CPU port of the reference's path, parity-pinned by tests/golden) on a bounded sample."""
+    """The oracle (CPU port of the reference's path, parity-pinned by tests/golden) on a bounded sample: steps of `sample_B`
+    episodes (the GPU's own batch where one such step fits the ~10-30 s budget) after a small warm-up step."""
     from oracle import gim_oracle as go
     import optimalstrategiesagainstgenerativeattacks_amd as G
     u = UNIT[workload]
-    # the GPU box gives one GPU a 16-CPU share whatever the affinity mask says: more threads only oversubscribe
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
+    cores, how = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(1)
     au, im = G.get_au(u["S"], u["C"], 512), G.get_im(u["S"], u["C"], 512)
@@ -234,16 +229,40 @@ def cpu_baseline(workload, m, n, k, sample_B):
     otr = go.OracleTrainer(au_sd, im_sd, n, 1e-4, 1e-4, 1e-6)
     leaked, real, si = synthetic_batch(sample_B, m, n, k, u["C"], u["S"], "cpu", 1234)
     z = torch.randn(sample_B, n, 512)
-    otr.step(leaked, real, si, z)  # warm-up
+    wb = min(2, sample_B)
+    t0 = time.time()
+    otr.step(leaked[:wb], real[:wb], si[:wb], z[:wb])  # warm-up (thread pool, allocator) on two episodes
+    warm = time.time() - t0
+    # a step of sample_B episodes costs ~ warm * sample_B / wb: if one such step would blow the budget, time the small batch instead
+    if warm * sample_B / wb > 45.0:
+        sample_B = wb
+        leaked, real, si, z = leaked[:wb], real[:wb], si[:wb], z[:wb]
     t0 = time.time()
     steps = 0
-    while steps < 3 or (time.time() - t0 < 10.0 and steps < 40):   # about 10 s of CPU work
+    while steps < 1 or (time.time() - t0 < 10.0 and steps < 40):   # about 10-30 s of CPU work
         otr.step(leaked, real, si, z)
         steps += 1
     dt = time.time() - t0
     return {"value": round(sample_B * steps / dt, 4), "unit": "episodes/s", "cores": cores, "kind": "port",
-            "sample": "%d timed steps (%.1f s, after 1 warm-up) of B=%d episodes of the same workload, torch-CPU eager fp32, %d threads"
-                      % (steps, dt, sample_B, cores)}
+            "sample": "%d timed step(s) (%.1f s, after a %d-episode warm-up step) of B=%d episodes of the same workload, torch-CPU eager "
+                      "fp32, %d threads (%s)" % (steps, dt, wb, sample_B, cores, how)}
+
+
+def host_cores():
+    """Threads the CPU baseline may use: the cgroup CPU quota of this container when there is one (a GPU box gives one GPU a share
+    of the host whatever the affinity mask says: more threads only oversubscribe), else the affinity mask."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            return min(aff, q), "cgroup cpu.max %s/%s, affinity mask %d" % (quota, period, aff)
+    except (OSError, ValueError):
+        pass
+    cap = int(os.environ.get("GIM_CPU_BASELINE_THREADS", "0"))
+    if cap > 0:
+        return min(aff, cap), "GIM_CPU_BASELINE_THREADS=%d, affinity mask %d" % (cap, aff)
+    return min(aff, 64), "affinity mask %d, no cgroup quota" % aff
 
 
 def main():
@@ -258,7 +277,6 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-bf16x3", action="store_true", help="accepted and ignored (round-2 scripts): the bf16x3 matrix path was removed in round 3")
     ap.add_argument("--reg-param", type=float, default=0.0, help="R1 weight (BASELINE's metric is quoted at 0; 10 = the paper's VoxCeleb2 setting)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only: argument parsing, process group, one all-reduce, JSON line")
     ap.add_argument("--inner", action="store_true", help="(used by the traffic passes) run the steps and print nothing else")
     args = ap.parse_args()
@@ -273,6 +291,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    # a core set per rank, before anything touches the GPU (the runtime's helper threads inherit the mask)
+    from optimalstrategiesagainstgenerativeattacks_amd.training_utils import pin_rank_to_cores
+    pinned = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     # rehearsal knobs for a 1-GPU box / the CPU tests: GIM_BENCH_BACKEND=gloo; GIM_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0
     backend = os.environ.get("GIM_BENCH_BACKEND", "nccl")
 
@@ -293,7 +314,7 @@ def main():
 
     # HBM traffic first: the profiled runs are child processes and this process has not touched the GPU yet
     traffic, traffic_note = None, "not measured"
-    if world == 1 and not (args.no_traffic or args.inner or args.graph or os.environ.get("GIM_BENCH_NO_TRAFFIC")):
+    if world == 1 and not (args.no_traffic or args.inner or os.environ.get("GIM_BENCH_NO_TRAFFIC")):
         traffic, traffic_note = measure_hbm_traffic(args)
         log("HBM traffic: %s" % (traffic["hbm_bytes_per_step"] if traffic else traffic_note))
 
@@ -314,17 +335,14 @@ def main():
     leaked, real, si = synthetic_batch(B, m, n, k, u["C"], u["S"], device, 1234 + rank)
     zgen = torch.Generator(device=device).manual_seed(4321 + rank)
 
-    graphed = None
-    if args.graph:
-        from optimalstrategiesagainstgenerativeattacks_amd.graph import GraphedGimStep
-        graphed = GraphedGimStep(trainer, leaked, real, si, torch.randn((B, n, 512), device=device, generator=zgen))
+    # do the engine's streams run concurrently here (one hardware queue each)?  warns loudly when they do not
+    streams_check = G.stream_concurrency_check(device)
+    log("stream self-check: %s" % streams_check)
 
     def step():
         z = torch.randn((B, n, 512), device=device, generator=zgen)
         tr.do_global_step()
         tr.update_learning_rate()
-        if graphed is not None:
-            return graphed(leaked, real, si, z)
         return G.gim_step(trainer, leaked, real, si, z=z, defer_join=True)   # joined by the next step / the final synchronize
 
     def fence():
@@ -349,6 +367,7 @@ def main():
         torch.cuda.synchronize()
         log("%s: %d warm-up steps done" % (label, args.warmup))
         gc.collect()   # start the timed region with an empty young generation (a full collection mid-region stalls the enqueue thread)
+        tr.impersonator_opt.allreduce_timing, tr.authenticator_opt.allreduce_timing = [], []
         fence()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cur = torch.cuda.current_stream()
@@ -366,11 +385,21 @@ def main():
         ts = [ev0.elapsed_time(mk) for mk in marks]
         per_step = [b - a for a, b in zip([0.0] + ts[:-1], ts)]
         log("%s: timed region done: %.3f s for %d steps" % (label, dt, args.steps))
+        # the gradient all-reduces as the step saw them (events on the stream that issued them: the generator's on the caller's
+        # stream right after its backward, under the discriminator step; the discriminator's on lane 1, under the next generator forward)
+        ar = {}
+        for name, opt in (("g", tr.impersonator_opt), ("d", tr.authenticator_opt)):
+            ts_ = [a.elapsed_time(b) for a, b in (opt.allreduce_timing or [])]
+            ar[name] = round(sum(ts_) / len(ts_), 4) if ts_ else None
+            ar[name + "_bucket_bytes"] = int(opt.flat_g.numel()) * 4 if getattr(opt, "_built", False) else None
+            opt.allreduce_timing = None
+        ranks_dt = [dt]
         if world > 1:
-            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        return dt, dev_ms, per_step, out
+            tall = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(tall, torch.tensor([dt], device=device, dtype=torch.float64))
+            ranks_dt = [float(t_.item()) for t_ in tall]
+            dt = max(ranks_dt)
+        return dt, dev_ms, per_step, out, ar, ranks_dt
 
     if args.inner:   # a traffic pass: the steps only
         for _ in range(args.warmup + args.steps):
@@ -387,7 +416,7 @@ def main():
     exe_gf, algo_launch_gf, per_conv = summarize_flops(counts, _ops)
 
     matrix_path = "fp32 MFMA"
-    dt, dev_ms, per_step, out = timed(matrix_path)
+    dt, dev_ms, per_step, out, allreduce_ms, ranks_dt = timed(matrix_path)
     g_loss, d_loss = float(out[0][0]), float(out[1][0])
 
     if rank == 0:
@@ -404,11 +433,18 @@ def main():
             "ms_per_step_median": round(med, 3), "value_at_median_step": round(B * world / med * 1e3, 3),
             "per_step_ms": [round(t, 2) for t in per_step],   # device time between consecutive steps on the caller's stream (rank 0)
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            # multi-GPU attribution: per-rank step times of the same timed region (value uses the max), the gradient all-reduces as
+            # the step sees them (ms per step; null without a communicator), the hardware-queue setting in force and the result of
+            # the start-up spin test of the engine's streams, the cores this rank pinned itself to
+            "ms_per_step_ranks": {"min": round(min(ranks_dt) / args.steps * 1e3, 3), "max": round(max(ranks_dt) / args.steps * 1e3, 3)},
+            "allreduce_ms": allreduce_ms,
+            "hw_queues": dict(G.hw_queues_state(), streams_check=streams_check),
+            "cpu_affinity": pinned,
             "config": {"workload": "%s: %dx%dx%d synthetic episodes, m=%d n=%d k=%d, %d episodes/GPU, style_dim=512, "
                                    "G step + D step + 2 Adam updates per step, reg_param=%g" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B, args.reg_param),
                        "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world,
                        "backend": dist.get_backend() if dist.is_initialized() else None,
-                       "launch": "hipGraph replay" if args.graph else "eager", "matrix_path": matrix_path},
+                       "launch": "eager", "matrix_path": matrix_path},
             "roofline": {"bound": "mfma", "achieved": round(executed, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
                          "what": "achieved / frac: FLOPs the kernels EXECUTE per second (every conv / linear / batched-GEMM launch of one step "
@@ -430,7 +466,7 @@ def main():
             line["dominant_kernel"] = dominant_kernel_roofline(per_conv, device)
             log("kernel microbenchmark done")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, m, n, k, sample_B=2)
+            line["cpu_baseline"] = cpu_baseline(args.workload, m, n, k, sample_B=B)
             log("cpu baseline done")
             line["cpu_baseline"]["gpu_over_cpu"] = round(eps / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line))

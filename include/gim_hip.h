@@ -356,6 +356,11 @@ int gim_img_att_mix_bwd(const float* dout, const float* q1, const float* k1, con
 int gim_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end, const float* lr,
                   int n_seg, float beta1, float beta2, float eps, float grad_scale, int32_t* step, void* stream);
 
+/* Stream self-check: one wave busy for `usec` microseconds (1 .. 5000, constant 100 MHz wall clock) on `stream`.  The host
+ * launches one per engine stream at the same moment and event-times the total: streams that share a HIP hardware queue serialize
+ * (nn.DataParallel's one-thread-per-device streams of training/gim_img_training.py:406-411 have no such aliasing to check). */
+int gim_spin(int usec, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,7 @@ SIGNATURES = {
     "gim_img_att_mix_fwd": [P, P, P, P, P, P, P, P, c_int64, c_int, P],
     "gim_img_att_mix_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, P],
     "gim_adam_step": [P, P, P, P, c_int64, P, P, c_int, c_float, c_float, c_float, c_float, P, P],
+    "gim_spin": [c_int, P],
     "gim_version": [],
 }
 

@@ -1825,6 +1825,7 @@ static bool launch_patch(const ConvP& p, size_t y_elems, hipStream_t st, int wan
     if (BMODE == 1 && p.Cb % 4 != 0) return false;
     const int HW = g.H * g.W;
     if (HW < 64) return false;
+    if (g.W < 2) return false;   // a one-pixel-wide map of >= 128 rows: (BM / W + 2) * (W + 2) patch pixels would exceed the P_PER quads a thread stages
     // tile: the caller's / table's choice, else as launch_igemm's heuristic; 128-row tiles need H * W >= 128 and W <= 64
     int cfg = want;
     if (cfg == 6432) cfg = 64;
@@ -2282,8 +2283,9 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
         if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
     }
     // plain 3x3, row-resident kernel: on request (tile code >= 20000 from the caller or the table row; ks / target = workgroups wanted)
+    // (W >= 4: the narrowest instantiation walks rows of 4 pixels - a non-square 8 x 2 map passes H * W >= 16 and must not run it)
     if (q.patch && atomic && s->KH == 3 && !s->wfold && !s->ups && !s->pool && s->Cin % 32 == 0 && s->Cout % 128 == 0 && s->H * s->W >= 16 &&
-        !((uintptr_t)dy & 15) && !((uintptr_t)x & 15)) {
+        s->W >= 4 && !((uintptr_t)dy & 15) && !((uintptr_t)x & 15)) {
         const int tiles = 3 * (s->Cin / 32) * (s->Cout / 128);
         long long S = ((q.patch_target > 0 ? q.patch_target : 1024) + tiles - 1) / tiles;
         const long long maxS = (q.M + 127) / 128;          // at least 8 steps per slice

@@ -902,3 +902,20 @@ extern "C" int gim_colsum_acc(const float* x, float* out, float* scratch, int64_
     hipLaunchKernelGGL(colsum_final_acc_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)P, C);
     return gim_check_launch("gim_colsum_acc");
 }
+
+// ---------------------------------------------------------------- stream self-check
+// One wave that keeps a compute unit busy for `usec` microseconds of the constant 100 MHz wall clock (s_memrealtime), capped at
+// 5 ms: every wave reaches the exit.  ops.stream_concurrency_check launches one per engine stream at the same time: streams that
+// HIP dealt onto ONE hardware queue run their kernels one after the other (GPU_MAX_HW_QUEUES, profiles/r03_q_hw_queue_sweep.txt),
+// which the event-timed total shows.
+__global__ __launch_bounds__(64) void spin_kernel(unsigned ticks, unsigned* sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned n = 0;
+    while (wall_clock64() - t0 < ticks) ++n;
+    if (sink && threadIdx.x == 0) *sink = n;
+}
+extern "C" int gim_spin(int usec, void* stream) {
+    GIM_CHECK_ARG(usec > 0 && usec <= 5000, "spin: 1 .. 5000 microseconds");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)usec * 100u, (unsigned*)nullptr);
+    return gim_check_launch("gim_spin");
+}

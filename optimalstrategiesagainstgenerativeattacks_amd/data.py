@@ -139,6 +139,21 @@ class EpisodeBank(torch.utils.data.Dataset):
         return len(self) // batch_size if drop_last else -(-len(self) // batch_size)
 
 
+class OmniglotEpisodeBank(EpisodeBank):
+    """The sample contract of the reference's ``OmniglotGIMDataSet`` (data_handling/img_datasets.py:118-215) on the resident bank:
+    one-channel ('L' mode) images, NO mirroring (its ``augment_transforms`` is None), at most ``NUM_EXAMPLES_PER_CLASS`` = 20
+    images drawn per episode - ``m + n + si`` beyond that raises the reference's ValueError - and ``class_name`` =
+    "alphabet/character".  Everything else (index -> class, distinct images of one class, [-1, 1] range) is EpisodeBank's."""
+    NUM_EXAMPLES_PER_CLASS = 20
+
+    def __init__(self, images_u8, class_offsets, m, n, si, example_cnt_per_class=1, class_names=None, seed=0):
+        if m + n + si > self.NUM_EXAMPLES_PER_CLASS:
+            raise ValueError("Max allowed value for m+n+si is {}".format(self.NUM_EXAMPLES_PER_CLASS))
+        if images_u8.dim() == 4 and images_u8.shape[3] != 1:
+            raise RuntimeError("OmniglotEpisodeBank: one-channel images expected (the reference loads Omniglot in mode 'L')")
+        super().__init__(images_u8, class_offsets, m, n, si, example_cnt_per_class, mirror=False, class_names=class_names, seed=seed)
+
+
 def synthetic_bank(n_classes, imgs_per_class, S, C, device, seed=0):
     """Random uint8 image bank (benchmarks / tests)."""
     g = torch.Generator().manual_seed(seed)

@@ -2,12 +2,18 @@
 ``training/gim_gaussian_training.py`` - ``im_train_step`` (:20-30), ``au_train_step`` (:33-47), ``train`` (:50-151),
 ``train_gim_gaussian`` (:154-235) - with the same signatures, logger keys and cadences.
 
-Sampling follows the reference draw for draw: per iteration the source means ``mu ~ N(0, prior_sigma)`` and then the real,
-leaked and registration sets ``~ N(mu, src_sigma)`` come from torch's DEFAULT (host) generator, in that order, and are moved
-to the device (the reference builds them on the CPU and calls ``.to(device)``, :66-81).  ``host_noise=True`` also draws the
-impersonator's latent ``z`` (models/gim_gaussian_models.py:81) from the host generator right behind them - the stream a
-CPU run of the reference consumes, which is what the parity fixture pins; by default ``z`` is drawn on the device, as the
-reference does on a GPU.
+Sampling: per iteration the source means ``mu ~ N(0, prior_sigma)`` and then the real, leaked and registration sets
+``~ N(mu, src_sigma)``, in that order, all from torch's DEFAULT HOST generator, then moved to the device.  That is the
+reference's stream when it runs on a CPU (:72-86) - the case BASELINE config 1 names and the parity fixture pins.  (On
+``cuda`` the reference moves ``mu`` to the device first, so there its three sample sets come from the DEVICE generator; the
+engine keeps the host draws on the GPU too: one documented stream instead of two.)  ``host_noise=True`` also draws the
+impersonator's latent ``z`` (models/gim_gaussian_models.py:81) from the host generator right behind them - what a CPU run of
+the reference consumes; by default ``z`` is drawn on the device.
+
+Data parallel (``EpisodeParallel``, torch.distributed initialised): every rank draws the SAME global batch of ``batch_size``
+episodes - the ranks must seed the host generator identically, as ``train_gim_on_gaussians.py:6`` does with
+``torch.manual_seed`` - and keeps its own slice (``trainer.shard``): ONE batch of ``batch_size`` scattered over the GPUs, what
+``nn.DataParallel`` does in the reference (:198-201), not ``world * batch_size``.
 """
 import os
 
@@ -44,6 +50,9 @@ def train(device, trainer, logger, n_iters, batch_size, src_dim, src_sigma, prio
         m, n, k = mod.m, mod.n, mod.k
         mu, sigma, (real_sample, leaked_sample, si_sample) = _draw_sets(batch_size, src_dim, src_sigma, prior_sigma, (n, m, k), device)
         z = torch.randn((batch_size, n, src_dim), dtype=torch.float32).to(device) if host_noise else None
+        if getattr(trainer, "world_size", 1) > 1:   # one global batch, scattered over the ranks (identical host seeds: see above)
+            mu, sigma, real_sample, leaked_sample, si_sample = trainer.shard(mu, sigma, real_sample, leaked_sample, si_sample)
+            z = trainer.shard(z) if z is not None else None
         global_step = mod.get_global_step()
 
         im_res, au_res = gim_step(trainer, leaked_sample, real_sample, si_sample, z=z)

@@ -49,7 +49,6 @@ def _use_side_streams(t):
 _STREAM_MAP = [int(v) for v in os.environ.get("GIM_STREAM_MAP", "0,1,2,2,0").split(",")]
 assert len(_STREAM_MAP) == 5, "GIM_STREAM_MAP: five comma-separated stream ids (roles 0..4)"
 _POOL = {}
-GROUP_STYLE_LINEARS = [True]   # the generator's 36 style projections as one grouped launch (AdaInImage2Image.forward)
 
 
 def _role_stream(device, role):
@@ -76,6 +75,52 @@ def lane_stream(device, lane):
     """The main stream of lane 1 (lane 0 runs on the caller's current stream)."""
     assert lane == 1
     return _role_stream(device, 2)
+
+
+def stream_concurrency_check(device, usec=300, warn=True):
+    """Do the engine's streams (the caller's + the role streams above) run CONCURRENTLY on this process's HIP runtime?
+    One `usec`-microsecond single-wave spin kernel (gim_spin) is launched on every distinct stream at the same moment and the
+    total is event-timed against one spin alone: streams that HIP dealt onto the same hardware queue run their kernels one after
+    the other (GPU_MAX_HW_QUEUES, read by the runtime when it starts: 4 by default - two of the step's streams on one queue cost
+    6-12 % of the step, profiles/r03_q_hw_queue_sweep.txt; how streams alias depends on how many exist, a real 8-rank RCCL
+    communicator creates more than a one-rank rehearsal).  Returns {"streams", "one_ms", "all_ms", "serialization" (all / one:
+    1 = fully concurrent, >= 2 = at least two streams share a queue), "concurrent", "GPU_MAX_HW_QUEUES"} and warns loudly when
+    the streams serialize.  Costs < 2 ms; bench.py and train_gim_imgs run it once at start-up."""
+    import warnings
+    from . import _lib
+    lib = _lib.load()
+    cur = torch.cuda.current_stream(device)
+    streams, seen = [cur], {cur.cuda_stream}
+    for role in range(5):
+        st = _role_stream(device, role)
+        if st.cuda_stream not in seen:
+            seen.add(st.cuda_stream)
+            streams.append(st)
+
+    def run(sts):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for st in sts[1:]:
+            st.wait_stream(cur)
+        for st in sts:
+            _lib.check(lib.gim_spin(usec, st.cuda_stream), "spin")
+        for st in sts[1:]:
+            cur.wait_stream(st)
+        e1.record(cur)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    run(streams)                      # first launch of the kernel / first use of the streams
+    one = min(run(streams[:1]) for _ in range(3))
+    alls = min(run(streams) for _ in range(3))
+    ser = alls / max(one, 1e-6)
+    res = {"streams": len(streams), "one_ms": round(one, 4), "all_ms": round(alls, 4), "serialization": round(ser, 2),
+           "concurrent": ser < 1.5, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+    if warn and not res["concurrent"]:
+        warnings.warn("GIM engine: its %d HIP streams do NOT run concurrently (spin test: %.2f ms together vs %.2f ms alone): at least two "
+                      "share a hardware queue and the training step will be 6-12 %% slower.  Set GPU_MAX_HW_QUEUES=8 in the environment "
+                      "BEFORE the process makes its first GPU call (importing this package first does it)." % (len(streams), alls, one),
+                      RuntimeWarning, stacklevel=2)
+    return res
 
 
 class Encoder(nn.Module):
@@ -231,6 +276,8 @@ class AdaInImage2Image(nn.Module):
         self.adain_res_block = Img2ImgAdaInResModule(style_dim=style_dim, n_blocks=n_adain_res_blocks)
         self.adain_up_block = Img2ImgAdaInUpModule(img_size=img_size, img_channels=out_channels, style_dim=style_dim,
                                                    min_n_channels=min_n_channels)
+        # the 36 style projections as ONE grouped launch (ops.GroupedLinearFn); a per-module switch (plain attribute, not state)
+        self.group_style_linears = True
 
     def forward(self, x, style):
         # the 36 style linears (tiny, latency-bound GEMMs) depend on `style` only: run them all now on a side stream,
@@ -241,9 +288,10 @@ class AdaInImage2Image(nn.Module):
             side = _side_streams(x.device)[0]
             ops.stream_wait(side, cur)
             with torch.cuda.stream(side):
-                if not GROUP_STYLE_LINEARS[0]:
-                    # (the grouped launch addresses its outputs and gradients through job tables built per allocation; a process
-                    #  that captures hipGraphs - graph.GraphedGimStep clears the switch before its warm-up - runs the layers one by one)
+                if not self.group_style_linears or ops.deterministic():
+                    # (the grouped launch addresses its outputs and gradients through job tables built per allocation and adds the
+                    #  36 input gradients with float atomics: a hipGraph capture - tools/graph_replay_experiment.py - and the
+                    #  deterministic mode run the layers one by one)
                     svs_res = [b.style_vectors(style) for b in self.adain_res_block.res_blocks]
                     svs_up = [b.style_vectors(style) for b in self.adain_up_block.up_blocks]
                 else:

@@ -293,7 +293,12 @@ def train_gim_imgs(device_name, device_ids, outdir, train_ds, val_ds, authentica
     launch one process per GPU (torchrun) - each process builds the same trainer, takes its slice of every global batch
     and the two optimizers all-reduce their gradient buckets over RCCL (EpisodeParallel replaces nn.DataParallel)."""
     from .gim_img_trainer import GIMImgTrainer
+    from .gim_img_models import stream_concurrency_check
+    from .training_utils import pin_rank_to_cores
+    if dist.is_initialized() and not torch.cuda.is_initialized():
+        pin_rank_to_cores()   # a core set per rank, before the first GPU call (the runtime's helper threads inherit it)
     device = get_device(device_type=device_name, device_ids=device_ids)
+    stream_concurrency_check(device)   # warns when the engine's streams share a hardware queue (GPU_MAX_HW_QUEUES not in force)
     rank, world = _world()
     n_devices = world if dist.is_initialized() else 1
     assert batch_size % n_devices == 0

@@ -122,9 +122,32 @@ def weight_phys(w):
 # Deterministic weight-gradient combine (slabs + fixed-order reduce) instead of float atomics, for the non-queued path
 _WGRAD_SLABS = os.environ.get("GIM_WGRAD_SLABS") is not None
 
+# Deterministic mode (host switch GIM_DETERMINISTIC=1 at import, or set_deterministic()): the reference's path is reproducible
+# from run to run (torch on the CPU, training/gim_img_training.py:157-183); the engine's default is not in its last bits, because
+# three of its sums are combined with float atomics whose order varies: the K slices of forward / dgrad launches that split K,
+# the pixel slices of a weight gradient (and the jobs of one gradient in the batched finish), the grouped style projections'
+# input gradient.  Under the switch no launch splits K (tune_ksplit = 1 on every forward / dgrad shape), weight gradients go the
+# non-queued way as slabs added in a fixed order (the GIM_WGRAD_SLABS path), and the style projections run one by one (autograd
+# adds their gradients in graph order): two runs of one program are bit-identical, at ~25 % of the speed of the default
+# (tests/test_gpu_models.py::test_deterministic_mode_is_bit_reproducible).
+_DETERMINISTIC = [os.environ.get("GIM_DETERMINISTIC") is not None]
+
+
+def deterministic():
+    return _DETERMINISTIC[0]
+
+
+def set_deterministic(flag):
+    """Switch the deterministic mode (see above) on or off; returns the previous setting."""
+    prev = _DETERMINISTIC[0]
+    _DETERMINISTIC[0] = bool(flag)
+    if prev != _DETERMINISTIC[0]:
+        _SPLITS_K.clear()    # the cached "does this launch split K" answers were given for the other mode
+    return prev
+
 
 def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
-    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, 0, 0, 0, 0)
+    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, 0, 1 if _DETERMINISTIC[0] else 0, 0, 0)
 
 
 # Launch overrides for tools/step_autotune.py (tuning the launch table against the time of the WHOLE overlapped step instead of
@@ -594,7 +617,7 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
     dw = db = None
     Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
     ns = 1   # pixel slices combined with float atomics; GIM_WGRAD_SLABS=1: deterministic slabs (non-queued path only)
-    if _WGRAD_SLABS:
+    if _WGRAD_SLABS or _DETERMINISTIC[0]:
         ns = lib.gim_conv2d_wgrad_slabs(sh)
         if ns <= 0:
             check(ns, "conv2d_wgrad_slabs")
@@ -607,7 +630,7 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
     # the finish kernels ADD into it and autograd gets None (no AccumulateGrad add kernel per parameter).
     acc_w = _grad_target(w) if (sigma is not None or not fold) and not torch.is_grad_enabled() else None
     acc_b = _grad_target(bias) if (slab_bias and acc_w is not None) else None
-    if acc_w is not None and wgrad_queue.enabled and not (want_b and slab_bias and acc_b is None):
+    if acc_w is not None and wgrad_queue.enabled and not _DETERMINISTIC[0] and not (want_b and slab_bias and acc_b is None):
         q = _queue()
         # deferred: raw gradient into an arena slot now, finish of all convs in two launches when backward ends
         n = Cout * K

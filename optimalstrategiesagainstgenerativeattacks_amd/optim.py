@@ -52,13 +52,21 @@ def _pad(n, align=64):
 _FORCE_ALLREDUCE = os.environ.get("GIM_FORCE_ALLREDUCE") is not None
 
 
-def all_reduce_grads_(flat_g):
+def all_reduce_grads_(flat_g, timing=None):
     """Data-parallel gradient exchange: ONE all-reduce(sum) of a flat gradient bucket over RCCL/xGMI (gloo in
     the CPU tests).  Each rank's bucket holds the gradient of its local mean loss, so the global-batch
     gradient is the returned scale (1/world_size) times the reduced bucket; the scale is folded into the
-    Adam kernel.  No-op (scale 1) when torch.distributed is not initialised."""
+    Adam kernel.  No-op (scale 1) when torch.distributed is not initialised.
+    timing: a list that receives (event before, event after) on the caller's stream per collective (bench.py: `allreduce_ms`;
+    the events bracket the collective as the STEP sees it - RCCL runs it on its own stream and the caller's stream waits for it)."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_ALLREDUCE):
-        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+        if timing is not None and flat_g.is_cuda:
+            cur = torch.cuda.current_stream()
+            e0 = cur.record_event(torch.cuda.Event(enable_timing=True))
+            dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+            timing.append((e0, cur.record_event(torch.cuda.Event(enable_timing=True))))
+        else:
+            dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
         return 1.0 / dist.get_world_size()
     return 1.0
 
@@ -71,6 +79,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._host_step = 0
         self._lr_cache = None
         self.grad_divisor = None  # set by dp: world size for the post-all-reduce average
+        self.allreduce_timing = None   # a list: step() appends the (before, after) events of its gradient all-reduce (bench.py)
 
     # ------------------------------------------------------------------ flat storage
     def _all_params(self):
@@ -173,7 +182,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._ensure()
         self._sync_grads()
         self._push_lrs()
-        scale = all_reduce_grads_(self.flat_g)
+        scale = all_reduce_grads_(self.flat_g, self.allreduce_timing)
         g0 = self.param_groups[0]
         for g in self.param_groups:
             assert g["betas"] == g0["betas"] and g["eps"] == g0["eps"], "one (betas, eps) per optimizer"

@@ -83,6 +83,30 @@ class EpisodeParallel(DataParallelMock):
                 dist.broadcast(t.data, src=0)
 
 
+def pin_rank_to_cores(local_rank=None, local_world=None):
+    """Give this rank a core set of its own: the ranks of one node are one Python process each, and each spends 25-30 ms of host
+    time per 38 ms step enqueueing kernels from two threads (the caller's and autograd's worker, profiles/r03_mid_host_profile.txt)
+    - eight of them migrating over one another's cores add jitter that shows as max-over-ranks step time.  The cores this
+    process may use (its affinity mask: a container's share) are dealt out in contiguous blocks by LOCAL_RANK; call it BEFORE
+    the first GPU call so that the runtime's helper threads inherit the mask.  (nn.DataParallel of the reference runs one
+    thread per device inside one process, training/gim_img_training.py:406-411: nothing to pin there.)
+    Returns the sorted core list now in force, or None when nothing was changed (one rank, no sched_setaffinity, fewer than
+    two cores per rank - a rank needs two threads)."""
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 2:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def get_device(device_type, device_ids, verbose=True):
     """training/utils.py:48-60.  One process drives ONE GPU here: under torch.distributed the device is this rank's
     (LOCAL_RANK), otherwise the smallest id of device_ids.  There is no CPU path: 'cpu' is refused."""

@@ -676,9 +676,76 @@ def gen_data():
     print("data.npz: %d arrays" % len(st))
 
 
+def gen_data_omniglot():
+    """The Omniglot sample contract (data_handling/img_datasets.py:118-215 OmniglotGIMDataSet): alphabet / character directories,
+    every image loaded ONCE at construction in mode 'L' (one channel) without augmentation, 20 images per character, an example =
+    m + n + si distinct images of one character drawn with random.sample, ValueError beyond 20.  The reference's class reads PNG
+    files written here from portable-fill uint8 images; the fixture holds the uint8 bank in the reference's own class order
+    (os.listdir order of the temporary tree, recorded), and per example the bank index of every returned image (exact match)
+    next to the returned float tensors.  Same torchvision stand-ins as gen_data (ToTensor only is touched)."""
+    import random
+    from PIL import Image
+    tvt = sys.modules["torchvision.transforms"]
+    if not hasattr(tvt, "ToTensor"):
+        class ToTensor:
+            def __call__(self, pic):
+                a = np.array(pic, dtype=np.uint8)
+                if a.ndim == 2:
+                    a = a[:, :, None]
+                return torch.from_numpy(a.transpose(2, 0, 1).copy()).float().div(255)
+        tvt.ToTensor = ToTensor
+    import data_handling.img_datasets as ids
+    S, m, n, k, per = 8, 1, 5, 10, 20
+    tree = {"alphaB": ["ch2", "ch1"], "alphaA": ["ch3"]}
+    with tempfile.TemporaryDirectory() as root:
+        for a_, chars in tree.items():
+            for ch in chars:
+                os.makedirs(os.path.join(root, "train", a_, ch))
+                for j in range(per):
+                    img = (pf.uniform("omni/%s/%s/%d" % (a_, ch, j), (S, S), 0.0, 256.0)).astype(np.uint8)
+                    Image.fromarray(img, "L").save(os.path.join(root, "train", a_, ch, "img%02d.png" % j))
+        ds = ids.OmniglotGIMDataSet(root=root, split="train", img_channels=1, img_size=S, m=m, n=n, si=k, example_cnt_per_class=3)
+        # the bank in the reference's class order; within a class in ITS file order (list_files = os.listdir order)
+        bank, offs, names = [], [0], []
+        for ci, character in enumerate(ds._characters):
+            names.append(character)
+            for img_name, _ in ds._character_images[ci]:
+                bank.append(np.array(Image.open(os.path.join(root, "train", character, img_name)).convert("L"), dtype=np.uint8)[:, :, None])
+            offs.append(len(bank))
+        bank = np.stack(bank)
+        st = {"bank": bank, "offsets": np.asarray(offs), "len": np.asarray(len(ds)), "n_classes": np.asarray(ds.n_classes)}
+        random.seed(5)
+        meta = []
+        for e, index in enumerate([0, 4, 8, 7]):
+            ex = ds[index]
+            ci = int(ex["class"])
+            meta.append({"index": index, "class": ci, "class_name": ex["class_name"]})
+            for part in ("leaked_sample", "real_sample", "si_sample"):
+                t = ex[part]
+                st["ex%d/%s" % (e, part)] = t.numpy()
+                src = []
+                for img in t:
+                    u8 = np.rint((img.numpy().transpose(1, 2, 0) + 1.0) * 127.5).astype(np.uint8)
+                    hit = [j for j in range(offs[ci], offs[ci + 1]) if np.array_equal(bank[j], u8)]
+                    assert len(hit) == 1, hit
+                    src.append(hit[0])
+                st["ex%d/%s/src" % (e, part)] = np.asarray(src, dtype=np.int32)
+        try:
+            ids.OmniglotGIMDataSet(root=root, split="train", img_channels=1, img_size=S, m=1, n=10, si=10, example_cnt_per_class=1)
+            too_many = None
+        except ValueError as err:
+            too_many = str(err)
+    np.savez_compressed(os.path.join(OUT, "data_omniglot.npz"), **st)
+    with open(os.path.join(OUT, "data_omniglot.json"), "w") as f:
+        json.dump({"config": dict(S=S, C=1, m=m, n=n, k=k, per_class=per, example_cnt_per_class=3, python_random_seed=5),
+                   "class_names": names, "examples": meta, "too_many_error": too_many}, f)
+    print("data_omniglot.npz: %d arrays; classes %s" % (len(st), names))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "keys", "tiny", "trainer", "bench", "gaussian", "gaussloop", "subnets", "benchgrads", "ckpt", "loop", "data"]
+    which = sys.argv[1:] or ["blocks", "keys", "tiny", "trainer", "bench", "gaussian", "gaussloop", "subnets", "benchgrads", "ckpt", "loop", "data",
+                             "omniglot"]
     if "gaussian" in which:
         gen_gaussian()
     if "gaussloop" in which:
@@ -715,6 +782,8 @@ def main():
         gen_loop()
     if "data" in which:
         gen_data()
+    if "omniglot" in which:
+        gen_data_omniglot()
 
 
 if __name__ == "__main__":

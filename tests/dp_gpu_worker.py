@@ -14,6 +14,7 @@ from tests.helpers import episode, filled_sd, load_keys  # noqa: E402
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     n_iters = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+    tag = sys.argv[6] if len(sys.argv) > 6 else "dpg"
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,7 +33,7 @@ def main():
         trainer.broadcast_parameters()
     outs = []
     for it in range(n_iters):
-        leaked, real, si, z = [t.float().to(dev) for t in episode("dpg/%d" % it, B, m, n, k, c, s, d)]
+        leaked, real, si, z = [t.float().to(dev) for t in episode("%s/%d" % (tag, it), B, m, n, k, c, s, d)]
         if world > 1:
             leaked, real, si, z = trainer.shard(leaked, real, si, z)
         tr.do_global_step()

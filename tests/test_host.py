@@ -343,3 +343,128 @@ def test_episode_sampler_ranks_stay_in_step_over_epochs():
     a, _ = ranks[0].draw([1, 1], 0)
     b, _ = ranks[1].draw([1, 1], 1)
     assert not (a == b).all()      # ranks draw different images
+
+
+def test_deterministic_switch_forces_one_k_slice_and_slab_weight_gradients():
+    """ops.set_deterministic (GIM_DETERMINISTIC=1): every convolution shape carries tune_ksplit = 1, and the library then plans
+    ONE K slice (no float atomics) for a forward / dgrad launch that splits K by default; the weight-gradient path asks for slabs.
+    (Bit-reproducibility itself is a GPU test: tests/test_gpu_models.py::test_deterministic_mode_is_bit_reproducible.)"""
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib, ops
+    lib = _lib.load()
+
+    def plan(sh, kind):
+        out = (ctypes.c_int32 * 8)()
+        assert lib.gim_conv_launch_plan(ctypes.byref(sh), kind, ctypes.cast(out, ctypes.c_void_p)) == 0
+        return list(out)
+    prev = ops.set_deterministic(False)
+    try:
+        args = (80, 4, 4, 512, 512, 3, 0, 0.2)      # 80 images of 4 x 4 pixels: 1280 output pixels, K = 4608 - splits K by default
+        sh = ops._shape(*args)
+        assert sh.tune_ksplit == 0 and plan(sh, 0)[3] > 1 and plan(sh, 1)[3] > 1
+        assert ops.set_deterministic(True) is False and ops.deterministic()
+        sh = ops._shape(*args)
+        assert sh.tune_ksplit == 1 and plan(sh, 0)[3] == 1 and plan(sh, 1)[3] == 1
+        assert plan(sh, 0)[7] == 0      # and the tap-major loop (one K order whatever the batch): not the patch-resident kernel
+        assert lib.gim_conv2d_wgrad_slabs(ctypes.byref(sh)) >= 1
+    finally:
+        ops.set_deterministic(prev)
+    assert ops.deterministic() == prev
+
+
+def _pin_worker(rank, world, q):
+    from optimalstrategiesagainstgenerativeattacks_amd.training_utils import pin_rank_to_cores
+    before = sorted(os.sched_getaffinity(0))
+    got = pin_rank_to_cores(rank, world)
+    q.put((rank, before, got, sorted(os.sched_getaffinity(0))))
+
+
+@pytest.mark.skipif(not hasattr(os, "sched_setaffinity") or len(os.sched_getaffinity(0)) < 4, reason="needs >= 4 cores to split")
+def test_ranks_pin_themselves_to_disjoint_core_sets():
+    """pin_rank_to_cores: the cores this job may use are dealt out in contiguous, disjoint blocks by LOCAL_RANK (bench.py and
+    train_gim_imgs call it before the first GPU call); one rank alone changes nothing."""
+    from optimalstrategiesagainstgenerativeattacks_amd.training_utils import pin_rank_to_cores
+    assert pin_rank_to_cores(0, 1) is None
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pin_worker, args=(r, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, before0, got0, after0), (_, before1, got1, after1) = res
+    assert before0 == before1 and got0 == after0 and got1 == after1
+    assert not set(got0) & set(got1) and len(got0) == len(got1) == len(before0) // 2
+    assert set(got0) | set(got1) <= set(before0)
+
+
+def test_hw_queue_default_is_reported():
+    """Importing the package before the first GPU call sets GPU_MAX_HW_QUEUES=8 unless the user chose a value; hw_queues_state()
+    says which value is in force and whether HIP had already been initialised (then the default could not take effect and the
+    import warns) - ADVICE r03; bench.py prints it with the result of the start-up spin test of the engine's streams."""
+    import subprocess
+    code = ("import os, json, warnings\n"
+            "os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
+            "import optimalstrategiesagainstgenerativeattacks_amd as G\n"
+            "print(json.dumps(G.hw_queues_state()))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st == {"GPU_MAX_HW_QUEUES": "8", "preset_by_user": False, "hip_initialised_before_import": False}
+    r = subprocess.run([sys.executable, "-c", code.replace("os.environ.pop('GPU_MAX_HW_QUEUES', None)", "os.environ['GPU_MAX_HW_QUEUES'] = '4'")],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st["GPU_MAX_HW_QUEUES"] == "4" and st["preset_by_user"]
+
+
+def test_gaussian_loop_scatters_one_global_batch_over_the_ranks(monkeypatch):
+    """train() of the Gaussian game under EpisodeParallel: every rank draws the SAME global batch (identical host
+    seeds) and trains on ITS slice - nn.DataParallel scatters one batch of batch_size (training/gim_gaussian_training.py:198-201) -
+    instead of every rank training on the whole batch.  The step itself is stubbed (it needs the GPU); what is checked is what the
+    step is handed, for world_size 2 against world_size 1."""
+    from optimalstrategiesagainstgenerativeattacks_amd import gim_gaussian_training as gg
+    from optimalstrategiesagainstgenerativeattacks_amd.training_utils import EpisodeParallel
+    seen = []
+
+    def fake_step(trainer, leaked, real, si, z=None):
+        seen.append((leaked.clone(), real.clone(), si.clone(), None if z is None else z.clone()))
+        B = leaked.size(0)
+        s0 = torch.zeros(())
+        return (s0, real, s0), (s0, s0, s0, s0, s0, s0, torch.ones(B, 1, dtype=torch.bool), torch.zeros(B, 1, dtype=torch.bool), real)
+    monkeypatch.setattr(gg, "gim_step", fake_step)
+
+    class Mod:
+        m, n, k = 1, 3, 4
+        gs = 0      # the first iteration is global step 1: no statistics / checkpoint cadence hit (those run GPU kernels)
+
+        def do_global_step(self):
+            self.gs += 1
+
+        def get_global_step(self):
+            return self.gs
+
+        def save(self):
+            pass
+
+    class Log:
+        def add_scalar(self, **kw):
+            pass
+    runs = {}
+    for world, rank in ((1, 0), (2, 0), (2, 1)):
+        tr = EpisodeParallel(Mod())
+        tr.world_size, tr.rank = world, rank
+        torch.manual_seed(11)
+        del seen[:]
+        gg.train(torch.device("cpu"), tr, Log(), n_iters=2, batch_size=6, src_dim=5, src_sigma=1.0, prior_sigma=2.0,
+                 save_stats_every=1000, save_every=1000, host_noise=True)
+        runs[(world, rank)] = list(seen)
+    for it in range(2):
+        whole = runs[(1, 0)][it]
+        for j in range(4):
+            assert whole[j].shape[0] == 6
+            both = torch.cat([runs[(2, 0)][it][j], runs[(2, 1)][it][j]])
+            assert torch.equal(both, whole[j]), (it, j)

@@ -109,7 +109,7 @@ def product():
     leaked, real, si, fake = mk(m), mk(n), mk(k), mk(n)
     z = torch.randn(B, n, D, device=dev, generator=g0)
     if case == "gimstep":
-        from optimalstrategiesagainstgenerativeattacks_amd.graph import GraphedGimStep
+        from graph_replay_experiment import GraphedGimStep   # tools/graph_replay_experiment.py (the experiment record)
         tr_e, trainer_e = make()
         gs = GraphedGimStep(trainer, leaked, real, si, z, warmup=3, overlap=True)
         # same number of eager steps on the twin
