@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_FP16_MFMA_TFLOPS = 2516.6  # 16x the fp32 MFMA rate (v_mfma_f32_32x32x16_f16: 32768 FLOP in 32 cycles per SIMD), ~2.5 PF dense
 # forward unit costs in GFLOP (2*MAC; conv + linear + attention bmm), style_dim = 512
 UNIT = {
     "om32": dict(S=32, C=1, E=1.2570, M=0.00210, Dec=0.2274, I2I=5.0189, FC=0.00944, H0=0.01468),
@@ -125,7 +126,7 @@ def measure_hbm_traffic(args, steps=2, warmup=1, timeout=420):
             d = os.path.join(tmp, ctr)
             cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "r", "--",
                    sys.executable, os.path.abspath(__file__), "--inner", "--workload", args.workload, "--batch", str(args.batch),
-                   "--steps", str(steps), "--warmup", str(warmup), "--reg-param", str(args.reg_param)]
+                   "--steps", str(steps), "--warmup", str(warmup), "--reg-param", str(args.reg_param), "--matrix-path", args.matrix_path]
             env = dict(os.environ, TMPDIR="/tmp")
             t0 = time.time()
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
@@ -180,6 +181,8 @@ def dominant_kernel_roofline(per, device):
     cfg = max(per, key=lambda c: per[c]["gflop"] * (per[c]["fwd"] + per[c]["dgrad"] + per[c]["wgrad"]))
     N, H, W, Cin, Cout, K, ups, pool, fold = cfg
     sh = _lib.GimConvShape(N, H, W, Cin, Cout, K, ups, 0.2, pool, fold, 0)
+    sh.prec = 1 if ops.matrix_path() == "fp16" else 0
+    peak = PEAK_FP16_MFMA_TFLOPS if sh.prec else PEAK_FP32_MFMA_TFLOPS
     KF = K + 1 if fold else K
     x = torch.randn(N, H >> ups, W >> ups, Cin, device=device)
     w = torch.randn(Cout, KF, KF, Cin, device=device) * 0.05     # folded layout when fold
@@ -205,10 +208,10 @@ def dominant_kernel_roofline(per, device):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         tf = gf / ms
-        out[name] = {"ms": round(ms, 4), "executed_tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+        out[name] = {"ms": round(ms, 4), "executed_tflops": round(tf, 2), "frac": round(tf / peak, 4)}
     return {"kernel": "conv N=%d %dx%d %d->%d %dx%d%s%s (%s)" % (N, H, W, Cin, Cout, K, K, ", avg-pool folded (stride-2, %dx%d taps)" % (KF, KF) if pool else "",
                                                               ", sub-pixel form of the upsampled conv" if (ups and fold) else "",
-                                                              "fp32 MFMA"),
+                                                              "fp16 operands" if sh.prec else "fp32 MFMA"),
             "launches_per_step": {k_: per[cfg][k_] for k_ in ("fwd", "dgrad", "wgrad")},
             "executed_gflop_per_launch": round(gf, 2),
             "algorithmic_gflop_per_launch": round(ops.conv_algorithmic_flops(*cfg) / 1e9, 2), **out}
@@ -277,6 +280,9 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-bf16x3", action="store_true", help="accepted and ignored (round-2 scripts): the bf16x3 matrix path was removed in round 3")
     ap.add_argument("--reg-param", type=float, default=0.0, help="R1 weight (BASELINE's metric is quoted at 0; 10 = the paper's VoxCeleb2 setting)")
+    ap.add_argument("--matrix-path", default="fp32", choices=["fp32", "fp16"],
+                    help="fp16: the opt-in 16-bit operand path (BASELINE config 5 'fp16 MFMA'; v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 master "
+                         "weights; eligible convolutions only).  BASELINE's metric and every parity bound are stated for fp32, the default")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only: argument parsing, process group, one all-reduce, JSON line")
     ap.add_argument("--inner", action="store_true", help="(used by the traffic passes) run the steps and print nothing else")
     args = ap.parse_args()
@@ -354,6 +360,7 @@ def main():
     import warnings
     warnings.filterwarnings("ignore")
     from optimalstrategiesagainstgenerativeattacks_amd import ops as _ops
+    _ops.set_matrix_path(args.matrix_path)
 
     def timed(label):
         """W warm-up steps, then EXACTLY K steps between barrier + synchronize;
@@ -415,7 +422,7 @@ def main():
         torch.cuda.synchronize()
     exe_gf, algo_launch_gf, per_conv = summarize_flops(counts, _ops)
 
-    matrix_path = "fp32 MFMA"
+    matrix_path = "fp32 MFMA" if args.matrix_path == "fp32" else "fp16 operands / fp32 accumulate on eligible convolutions (v_mfma_f32_32x32x16_f16), fp32 MFMA elsewhere"
     dt, dev_ms, per_step, out, allreduce_ms, ranks_dt = timed(matrix_path)
     g_loss, d_loss = float(out[0][0]), float(out[1][0])
 
@@ -425,11 +432,12 @@ def main():
         algo = algo_gflop_per_episode(args.workload, m, n, k)
         achieved = eps * algo / 1e3 / world            # ALGORITHMIC TFLOP/s per GPU (SURVEY.md 8(d) convention)
         executed = exe_gf / 1e3 / (dt / args.steps)     # EXECUTED TFLOP/s per GPU (this rank's launches)
+        PEAK = PEAK_FP32_MFMA_TFLOPS if args.matrix_path == "fp32" else PEAK_FP16_MFMA_TFLOPS
         line = {
             "metric": "GIM episodes/sec (%dx%dx%d, m=%d n=%d k=%d)" % (u["S"], u["S"], u["C"], m, n, k),
             "value": round(eps, 3), "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.matrix_path == "fp32" else "f16 operands, f32 accumulate / master weights", "data": "synthetic",
             "ms_per_step_median": round(med, 3), "value_at_median_step": round(B * world / med * 1e3, 3),
             "per_step_ms": [round(t, 2) for t in per_step],   # device time between consecutive steps on the caller's stream (rank 0)
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
@@ -445,17 +453,17 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world,
                        "backend": dist.get_backend() if dist.is_initialized() else None,
                        "launch": "eager", "matrix_path": matrix_path},
-            "roofline": {"bound": "mfma", "achieved": round(executed, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "achieved": round(executed, 3), "peak": PEAK, "unit": "TFLOP/s",
+                         "frac": round(executed / PEAK, 4),
                          "what": "achieved / frac: FLOPs the kernels EXECUTE per second (every conv / linear / batched-GEMM launch of one step "
                                  "counted per launch; the pool / sub-pixel folds run (K+1)^2 taps at a quarter of the pixels) over the fp32 MFMA "
                                  "peak = the matrix-pipe utilisation of the step (<= 1 by construction).  algo_tflops / algo_frac: the "
                                  "ALGORITHMIC figure of SURVEY.md 8(d) (the unfused reference ops at full resolution) - it counts taps the "
                                  "folded kernels never execute and can exceed 1; it is not a utilisation",
                          "algo_gflop_per_episode": round(algo, 1), "algo_gflop_per_step": round(algo * B, 1),
-                         "algo_tflops": round(achieved, 3), "algo_frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "algo_tflops": round(achieved, 3), "algo_frac": round(achieved / PEAK, 4),
                          "executed_gflop_per_step": round(exe_gf, 1), "executed_tflops": round(executed, 3),
-                         "executed_frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "executed_frac": round(executed / PEAK, 4),
                          "launched_ops_at_full_resolution_gflop_per_step": round(algo_launch_gf, 1),
                          "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
                          "traffic_unit": "HBM bytes/step", "traffic_detail": traffic if traffic else traffic_note,

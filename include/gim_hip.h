@@ -57,6 +57,10 @@ int gim_version(void);
  *   out_zeroed = 1: (gim_conv2d_fwd / _dgrad / _dgrad_t) the caller guarantees that the output buffer holds zeros.  Launches that
  *             split K over the grid combine their slices with float atomics and otherwise clear the output themselves (one
  *             memset per launch); a caller that hands out outputs from a zero-filled pool saves those launches.
+ *   prec       : 0 = fp32 operands on the fp32 MFMA (the reference's arithmetic, every parity bound); 1 = operands rounded to fp16
+ *                (nearest even, saturating) when they are staged into LDS, v_mfma_f32_32x32x16_f16 with fp32 accumulation - BASELINE
+ *                config 5 "fp16 MFMA", opt-in - on eligible launches only (gathered channels % 32 == 0, >= 32 output channels,
+ *                forward / gim_conv2d_dgrad_t / wgrad): gim_conv_launch_plan out[7] == 2 says a launch takes it.
  *   post_slope : (gim_conv2d_fwd only; 0 or 1 = none) LeakyReLU with this slope on the STORED output, y = lrelu(conv + bias +
  *             residual): the LeakyReLU that the reference applies in front of the NEXT conv (models/model_blocks.py:507), done
  *             once per element here instead of once per tap and output tile in that conv's K loop (which the caller then runs
@@ -69,6 +73,7 @@ typedef struct {
     int32_t tune_tile, tune_ksplit, tune_wgrad;
     int32_t out_zeroed;
     float post_slope;
+    int32_t prec;
 } gim_conv_shape;
 
 /* F[co][a][b][ci] = sum_{dh,dw in {0,1}} w[co][a-dh][b-dw][ci], a, b in [0, KH]  (out-of-range taps are zero). */

@@ -17,7 +17,7 @@ class GimConvShape(ctypes.Structure):
                 ("KH", c_int32), ("ups", c_int32), ("pre_slope", c_float),
                 ("pool", c_int32), ("wfold", c_int32), ("res_ups", c_int32),
                 ("tune_tile", c_int32), ("tune_ksplit", c_int32), ("tune_wgrad", c_int32),
-                ("out_zeroed", c_int32), ("post_slope", c_float)]
+                ("out_zeroed", c_int32), ("post_slope", c_float), ("prec", c_int32)]
 
 
 P = c_void_p

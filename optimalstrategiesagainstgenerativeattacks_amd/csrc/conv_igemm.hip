@@ -95,6 +95,7 @@ struct ConvP {
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
     int kper;     // K-steps per slice
+    int f16;      // host only: gim_conv_shape.prec == 1 - fp16 operands on v_mfma_f32_32x32x16_f16 where the launch is eligible (conv_f16.inc)
 };
 
 // GENF bit 0: generic K (channel count of the gathered tensor not a multiple of 16, or unaligned base)
@@ -1527,6 +1528,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row_kernel(const WgP p) {
     }
 }
 
+#include "conv_f16.inc"
+
 // -------------------------------------------------------------------------------------------------
 // folded weights: F[co][a][b][ci] = sum_{dh,dw in {0,1}} W[co][a-dh][b-dw][ci],  a, b in [0, K]
 // -------------------------------------------------------------------------------------------------
@@ -1551,28 +1554,60 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const float* __restri
     }
 }
 
-// all folds of a model in one launch: block b works on chunk tab[2b+1] (of 65536 elements) of job tab[2b]
+// all folds of a model in one launch: block b works on chunk tab[2b+1] (of 65536 elements) of job tab[2b].
+// (Round 4: 32-bit indices, the tap count a compile-time constant - its divisions become multiplies - and 16-byte loads / stores
+// along the channels when Cin % 4 == 0: the first version's three 64-bit divisions per ELEMENT made the two launches of a step
+// 0.53 ms at the head of the forward passes, ~4x the time of the bytes they move: profiles/r04_c_fold_weights_kernel.txt.)
+template <int KF_>   // taps per dimension of the folded kernel (K + 1); 0 = run-time value
+__device__ __forceinline__ void fold_chunk(const gim_fold_job& jb, unsigned lo, unsigned hi) {
+    const unsigned K = (unsigned)jb.KH, KF = KF_ ? (unsigned)KF_ : K + 1u, Cin = (unsigned)jb.Cin;
+    if ((Cin & 3u) == 0 && (((uintptr_t)jb.w | (uintptr_t)jb.f) & 15) == 0) {
+        const unsigned Cq = Cin >> 2;
+        const bool pow2 = (Cq & (Cq - 1u)) == 0;
+        const unsigned sh = 31u - (unsigned)__builtin_clz(Cq);
+        const f32x4* __restrict__ w4 = reinterpret_cast<const f32x4*>(jb.w);
+        f32x4* __restrict__ f4 = reinterpret_cast<f32x4*>(jb.f);
+        for (unsigned q = (lo >> 2) + threadIdx.x; q < (hi >> 2); q += 256) {
+            const unsigned rr = pow2 ? q >> sh : q / Cq, cq = pow2 ? q & (Cq - 1u) : q - rr * Cq;
+            const unsigned r2 = rr / KF, b = rr - r2 * KF;
+            const unsigned co = r2 / KF, a = r2 - co * KF;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (unsigned dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (unsigned dw = 0; dw < 2; ++dw) {
+                    const unsigned kh = a - dh, kw = b - dw;   // (unsigned wrap-around = out of range)
+                    if (kh < K && kw < K) acc += w4[((co * K + kh) * K + kw) * Cq + cq];
+                }
+            f4[q] = acc;
+        }
+        return;
+    }
+    for (unsigned i = lo + threadIdx.x; i < hi; i += 256) {
+        const unsigned rr = i / Cin, ci = i - rr * Cin;
+        const unsigned r2 = rr / KF, b = rr - r2 * KF;
+        const unsigned co = r2 / KF, a = r2 - co * KF;
+        float acc = 0.f;
+#pragma unroll
+        for (unsigned dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (unsigned dw = 0; dw < 2; ++dw) {
+                const unsigned kh = a - dh, kw = b - dw;
+                if (kh < K && kw < K) acc += jb.w[((co * K + kh) * K + kw) * Cin + ci];
+            }
+        jb.f[i] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void fold_weights_batched_kernel(const gim_fold_job* __restrict__ jobs, const int* __restrict__ tab) {
     const gim_fold_job jb = jobs[tab[2 * blockIdx.x]];
-    const int K = jb.KH, KF = K + 1, Cin = jb.Cin;
-    const long long n = (long long)jb.Cout * KF * KF * Cin;
-    const long long lo = (long long)tab[2 * blockIdx.x + 1] * 65536, hi = lo + 65536 < n ? lo + 65536 : n;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const int ci = (int)(i % Cin);
-        long long rr = i / Cin;
-        const int b = (int)(rr % KF); rr /= KF;
-        const int a = (int)(rr % KF);
-        const int co = (int)(rr / KF);
-        float s = 0.f;
-#pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-            for (int dw = 0; dw < 2; ++dw) {
-                const int kh = a - dh, kw = b - dw;
-                if (kh >= 0 && kh < K && kw >= 0 && kw < K) s += jb.w[(((long long)co * K + kh) * K + kw) * Cin + ci];
-            }
-        jb.f[i] = s;
-    }
+    const unsigned KF = (unsigned)jb.KH + 1u;
+    const unsigned n = (unsigned)jb.Cout * KF * KF * (unsigned)jb.Cin;     // < 2^31: checked on the host
+    const unsigned lo = (unsigned)tab[2 * blockIdx.x + 1] * 65536u, hi = lo + 65536u < n ? lo + 65536u : n;
+    if (KF == 4) fold_chunk<4>(jb, lo, hi);            // 3 x 3 convolutions
+    else if (KF == 10) fold_chunk<10>(jb, lo, hi);     // 9 x 9
+    else if (KF == 2) fold_chunk<2>(jb, lo, hi);       // 1 x 1
+    else fold_chunk<0>(jb, lo, hi);
 }
 
 extern "C" int gim_conv2d_fold_weights_batched(const gim_fold_job* jobs, const int32_t* tab, int n_blocks, void* stream) {
@@ -1660,6 +1695,7 @@ static int check_shape(const gim_conv_shape* s) {
     GIM_CHECK_ARG(!s->pool || (!s->ups && s->H >= 2 && s->W >= 2 && s->wfold), "conv: pool needs ups == 0, H, W >= 2 and folded weights");
     GIM_CHECK_ARG(!s->wfold || s->pool || s->ups, "conv: wfold only with pool or ups");
     GIM_CHECK_ARG((long long)s->N * s->H * s->W < (1ll << 31), "conv: too many output pixels");
+    GIM_CHECK_ARG(s->prec == 0 || s->prec == 1, "conv: prec must be 0 (fp32 MFMA) or 1 (fp16 operands, fp32 accumulate)");
     return GIM_OK;
 }
 
@@ -1884,12 +1920,53 @@ static bool launch_patch_s2(const ConvP& p, size_t y_elems, hipStream_t st, int 
     return true;
 }
 
+// fp16-operand launch (conv_igemm_f16_kernel): K steps of 32, tile by shape - the kernel is bound by operand traffic, so the largest
+// tile that still fills the chip; split-K as for the fp32 kernels.  No table rows (the table was measured on the fp32 kernels).
+template <int BM, int BN, int TM, int TN>
+static void launch_f16_cfg(ConvP p, size_t y_elems, hipStream_t st) {
+    const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
+    const int ncls = p.g.pc ? 4 : 1;
+    const int nk = p.Ktot / 32;
+    p.ksplit = plan_ksplit((long long)gx * gy * ncls, nk, BM * BN, p.tune_ks);
+    p.kper = (nk + p.ksplit - 1) / p.ksplit;
+    p.ksplit = (nk + p.kper - 1) / p.kper;
+    if (t_plan_out) {
+        const int32_t v[8] = {0, BM, BN, p.ksplit, gx, gy, p.ksplit * ncls, 2};
+        for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
+        return;
+    }
+    if (p.ksplit > 1 && p.post_slope != 1.f) {
+        gim_set_error("conv fwd: post_slope with a launch that splits K (ask gim_conv_launch_plan first)");
+        t_launch_refused = true;
+        return;
+    }
+    if (p.ksplit > 1 && !p.y_zeroed) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
+    hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, TM, TN>), dim3(gx, gy, p.ksplit * ncls), dim3(256), 0, st, p);
+}
+
+static bool launch_f16(const ConvP& p, size_t y_elems, hipStream_t st) {
+    if (p.Ca % 32 != 0 || p.Cb < 32 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return false;
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cb + 127) / 128) * (p.g.pc ? 4 : 1);
+    if (p.Cb > 64) {
+        if (p.M <= 64 || t128 < GIM_SMALL_TILES) launch_f16_cfg<64, 64, 1, 1>(p, y_elems, st);
+        else if (t128 < 256) launch_f16_cfg<64, 128, 1, 2>(p, y_elems, st);
+        else launch_f16_cfg<128, 128, 2, 2>(p, y_elems, st);
+    } else {
+        if (p.M <= 64 || t128 < GIM_SMALL_TILES) launch_f16_cfg<64, 64, 1, 1>(p, y_elems, st);
+        else launch_f16_cfg<128, 64, 2, 1>(p, y_elems, st);
+    }
+    return true;
+}
+
 // tile by shape (largest accumulator block the channel count fills); parallelism for small M comes from split-K.
 // tune_tile / tune_ks: the caller's explicit choice (gim_conv_shape.tune_tile / tune_ksplit; tune_tile < 0 = heuristics only),
 // else the table row of this shape, else the heuristic.
 template <int BMODE, int GEN>
 static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     const int M = p.M, Cb = p.Cb;
+    if constexpr (BMODE == 0 && GEN == 0) {
+        if (p.f16 && launch_f16(p, y_elems, st)) return;
+    }
     ConvP pt = p;
     const bool forced = p.tune_tile != 0 || p.tune_ks > 0;
     const TuneEntry* te = forced ? nullptr : tune_lookup(p.tune_kind, M, p.Ca, Cb, p.Ktot, p.g.pc);
@@ -1959,6 +2036,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     p.post_slope = (s->post_slope > 0.f) ? s->post_slope : 1.f;
     p.tune_kind = 0;
     p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit; p.y_zeroed = s->out_zeroed;
+    p.f16 = s->prec == 1;
     const size_t y_elems = (size_t)s->N * (s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
     GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: one image of the output exceeds 2 GiB (32-bit buffer offsets)");
     const bool gen = (s->Cin % BK) != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15);
@@ -2011,6 +2089,7 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
     hipStream_t st = (hipStream_t)stream;
     p.tune_kind = 1;
     p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit; p.y_zeroed = s->out_zeroed;
+    p.f16 = transposed && s->prec == 1;   // fp16 operands: the k-contiguous (transposed-weights) form only - ops.py routes fp16 dgrads there
     if (transposed) {
         // WT[ci][a][b][co]: the weight rows are k-contiguous (k = (tap, co)), i.e. the forward kernel's operand layout
         GIM_CHECK_ARG(!gen && !((uintptr_t)w & 15), "conv dgrad (transposed weights): Cout % 16 == 0 and 16-byte aligned operands required");
@@ -2085,7 +2164,7 @@ extern "C" int gim_conv2d_dgrad_xfold(const float* dy, const float* wx, const fl
 // stride 2 over the (K+1)^2 folded taps -> slabs in F layout [Cout][KF][KF][Cin].  sub-pixel (ups + wfold), roles
 // swapped: A = leaky_relu(x) [N,H/2,W/2,Cin], B = dy [N,H,W,Cout] gathered with stride 2 -> slabs
 // G[Cin][KF][KF][Cout] with G[ci][ta][tb][co] = dF[co][K-ta][K-tb][ci] (gim_wgrad_finish un-transposes).
-struct WgPlan { int bm, bn, ns, mper, rows, cols, M, table_hit, bk, patch, patch_target; };
+struct WgPlan { int bm, bn, ns, mper, rows, cols, M, table_hit, bk, patch, patch_target, f16; };
 
 static WgPlan wgrad_plan(const gim_conv_shape* s) {
     WgPlan q{};
@@ -2104,6 +2183,9 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
         if (te) { target = te->ks; tile = te->tile; q.table_hit = 1; }
     }
     if (tile >= 20000) { q.patch = 1; q.patch_target = target; tile -= 20000; }   // row-resident kernel (plain 3x3 layers)
+    // fp16 operands (conv_wgrad_f16_kernel): one tile shape, 32 pixels per K step; the table rows were measured on the fp32 kernels
+    const bool f16 = s->prec == 1 && q.rows % 4 == 0 && (up_fold ? s->Cout : s->Cin) % 4 == 0 && q.rows >= 32 && q.cols >= 64;
+    if (f16) { q.patch = 0; tile = 128; if (!(s->tune_wgrad > 0)) target = 0; q.f16 = 1; q.table_hit = 0; }
     q.bm = q.rows > 64 ? 128 : (q.rows > 32 ? 64 : 32);
     q.bn = (q.bm == 32) ? 128 : (q.cols > 64 ? 128 : 64);
     if (tile == 128) { q.bm = 128; q.bn = 128; }
@@ -2112,7 +2194,7 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     else if (tile == 64 || tile == 6432) { q.bm = 64; q.bn = 64; }
     else if (tile == 32128) { q.bm = 32; q.bn = 128; }
     // 32-pixel K steps: fp32 path, both operands on 16-byte loads (the launcher falls back to 16 otherwise)
-    q.bk = (tile == 6432 && q.rows % 4 == 0 && (up_fold ? s->Cout : s->Cin) % 4 == 0) ? 32 : BK;
+    q.bk = ((f16 || tile == 6432) && q.rows % 4 == 0 && (up_fold ? s->Cout : s->Cin) % 4 == 0) ? 32 : BK;
     const long long tiles = (long long)((q.cols + q.bn - 1) / q.bn) * ((q.rows + q.bm - 1) / q.bm);
     // Heuristic: about four workgroups per CU in total and at least 32 K-steps (512 pixels) per workgroup, so that the float
     // atomics of the combine stay small next to the MFMA work - unless that leaves most CUs idle (1x1 convs and linears on small
@@ -2120,7 +2202,12 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     // K step (~1.8 us), so short slices on many CUs win although they add more partial tiles (measured: tools/conv_autotune.py).
     // An explicit / table target lifts the 512-pixel floor to 64 (4 K-steps).
     long long minpix = 512;
-    if (!target) {
+    if (f16 && !target) {
+        // the fp16 kernel's K loop is 8x shorter per pixel than the fp32 one's, its epilogue (128 x 128 float atomics per workgroup:
+        // 64 KB) is not: half the workgroups, slices of >= 1024 pixels, unless that leaves the chip idle
+        target = 512;
+        minpix = (tiles * ((M + 1023) / 1024) < 256) ? 256 : 1024;
+    } else if (!target) {
         target = 1024;
         if (tiles * ((M + 511) / 512) < 256) minpix = 128;
     } else {
@@ -2329,7 +2416,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     p.xcd = (q.ns >= 64 || (q.ns >= 8 && q.ns % 8 == 0)) ? 1 : 0;   // every XCD gets (nearly) the same number of slices
     dim3 g((q.cols + q.bn - 1) / q.bn, (q.rows + q.bm - 1) / q.bm, p.xcd ? (q.ns + 7) / 8 * 8 : q.ns);   // z padded: wgrad_block
     if (t_plan_out) {
-        const int32_t v[8] = {q.table_hit, q.bm, q.bn, q.ns, (int32_t)g.x, (int32_t)g.y, (int32_t)g.z, 0};
+        const int32_t v[8] = {q.table_hit, q.bm, q.bn, q.ns, (int32_t)g.x, (int32_t)g.y, (int32_t)g.z, q.f16 ? 2 : 0};
         for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
         return GIM_OK;
     }
@@ -2339,6 +2426,11 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     const int bk = (q.bk == 32 && va && vb) ? 32 : BK;
     const bool fastb = vb && p.g.ups == 0 && ((p.g.H * p.g.W) & (bk - 1)) == 0;   // a K step stays inside one image
     hipStream_t st = (hipStream_t)stream;
+    if (q.f16 && va && vb && bk == 32) {
+        if (fastb) hipLaunchKernelGGL(conv_wgrad_f16_kernel<true>, g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(conv_wgrad_f16_kernel<false>, g, dim3(256), 0, st, p);
+        return gim_check_launch("gim_conv2d_wgrad");
+    }
     if (va && fastb) launch_wgrad<4, 4, true>(p, q.bm, q.bn, bk, g, st);
     else if (va && vb) launch_wgrad<4, 4, false>(p, q.bm, q.bn, bk, g, st);
     else if (va) launch_wgrad<4, 1, false>(p, q.bm, q.bn, bk, g, st);

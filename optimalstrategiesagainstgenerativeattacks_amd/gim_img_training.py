@@ -38,14 +38,24 @@ def au_eval_step(trainer, real_sample, fake_sample, si_sample):
             pred_on_real.detach(), pred_on_fake.detach(), fake_sample.detach())
 
 
+def _backward(loss):
+    """loss.backward() - on the fp16 matrix path of (loss * S), S = ops.loss_scale() (the optimizer step un-scales: FusedAdam.step
+    (grad_scale=1 / S)), so that the gradients the fp16 convolution kernels round stay inside fp16's precise range."""
+    s = ops.loss_scale()
+    if s != 1.0:
+        (loss * s).backward()
+    else:
+        loss.backward()
+
+
 def im_train_step(trainer, leaked_sample, si_sample, z=None):
     trainer.module.impersonator.train()
     trainer.module.impersonator_opt.zero_grad()
     loss, fake_sample, au_out = trainer.forward(mode='impersonator_forward', leaked_sample=leaked_sample,
                                                 si_sample=si_sample, **({} if z is None else {"z": z}))
     loss = loss.mean()
-    loss.backward()
-    trainer.module.impersonator_opt.step()
+    _backward(loss)
+    trainer.module.impersonator_opt.step(grad_scale=1.0 / ops.loss_scale())
     return loss.detach(), fake_sample.detach(), au_out.detach()
 
 
@@ -56,8 +66,8 @@ def au_train_step(trainer, real_sample, fake_sample, si_sample):
      fake_sample) = trainer.forward(mode='authenticator_forward', fake_sample=fake_sample, real_sample=real_sample,
                                     si_sample=si_sample)
     loss = loss.mean()
-    loss.backward()
-    trainer.module.authenticator_opt.step()
+    _backward(loss)
+    trainer.module.authenticator_opt.step(grad_scale=1.0 / ops.loss_scale())
     return (loss.detach(), loss_on_real.detach().mean(), loss_on_fake.detach().mean(), reg.detach().mean(),
             out_on_real.detach().mean(), out_on_fake.detach().mean(),
             pred_on_real.detach(), pred_on_fake.detach(), fake_sample.detach())
@@ -101,11 +111,11 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
         t.record_stream(dstream)
 
     # generator: backward on the caller's stream (enqueued first: it is the longer dependency chain)
-    loss.backward()
+    _backward(loss)
     gbwd_done = cur.record_event()
     # generator's Adam right away: nothing on lane 1 reads the generator's weights, and with several GPUs its gradient
     # all-reduce (the larger bucket, 246 MB) then runs under the discriminator step instead of after it
-    mod.impersonator_opt.step()
+    mod.impersonator_opt.step(grad_scale=1.0 / ops.loss_scale())
     im = (loss.detach(), fake_d, au_out.detach())
 
     # discriminator step on lane 1
@@ -116,9 +126,9 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
          fake_out) = trainer.forward(mode='authenticator_forward', fake_sample=fake_d, real_sample=real_sample,
                                      si_sample=si_sample)
         dloss = dloss.mean()
-        dloss.backward()
+        _backward(dloss)
         dstream.wait_event(gbwd_done)   # the generator's backward reads the weights this update overwrites
-        mod.authenticator_opt.step()
+        mod.authenticator_opt.step(grad_scale=1.0 / ops.loss_scale())
         au = (dloss.detach(), loss_on_real.detach().mean(), loss_on_fake.detach().mean(), reg.detach().mean(),
               out_on_real.detach().mean(), out_on_fake.detach().mean(),
               pred_on_real.detach(), pred_on_fake.detach(), fake_out.detach())

@@ -259,6 +259,8 @@ class SNPlan:
             for j, (c, _) in enumerate(todo):
                 KF = c.kernel_size + 1
                 n = c.out_channels * KF * KF * c.in_channels
+                if n >= 1 << 31:
+                    raise RuntimeError("folded weights of more than 2^31 elements (gim_conv2d_fold_weights_batched indexes with 32 bits)")
                 f = torch.empty(n, device=dev, dtype=torch.float32)
                 bufs.append(f)
                 jobs[j] = (c.weight_orig.data_ptr(), f.data_ptr(), c.out_channels, c.in_channels, c.kernel_size, 0)

@@ -146,8 +146,44 @@ def set_deterministic(flag):
     return prev
 
 
+# Matrix path of the convolutions: "fp32" (default: fp32 operands on the fp32 MFMA - the reference's arithmetic, what every parity
+# bound of north_star is stated for) or "fp16" (opt-in, BASELINE config 5 "fp16 MFMA"): operands rounded to fp16 when they are
+# staged into LDS, v_mfma_f32_32x32x16_f16 with fp32 accumulation, fp32 master weights and fp32 activations in HBM
+# (csrc/conv_f16.inc).  Host switch GIM_MATRIX_PATH=fp16 at import, or set_matrix_path(); launches that are not eligible (image
+# layers with 1 / 3 / 6 channels, < 32 output channels, linears) stay on the fp32 MFMA.
+_PREC = [1 if os.environ.get("GIM_MATRIX_PATH", "fp32") == "fp16" else 0]
+
+
+def matrix_path():
+    return "fp16" if _PREC[0] else "fp32"
+
+
+# Loss scale of the fp16 matrix path.  Gradients of a mean-over-episodes loss reach the convolutions at 1e-3 ... 1e-7 per element;
+# fp16 keeps 11 significant bits only down to 6.1e-5 (below that: subnormals, then zero).  The step functions (gim_img_training)
+# therefore differentiate loss * S and the fused Adam kernel multiplies the gradient bucket by 1 / S (a power of two: exact in
+# fp32, every backward operator is linear in the incoming gradient) - the standard mixed-precision recipe; not in the reference,
+# which has no 16-bit path.  Too-large values saturate at +-65504 when they are rounded (conv_f16.inc).  1 on the fp32 path.
+_LOSS_SCALE = [float(os.environ.get("GIM_FP16_LOSS_SCALE", "4096"))]
+
+
+def loss_scale():
+    return _LOSS_SCALE[0] if _PREC[0] else 1.0
+
+
+def set_matrix_path(name):
+    """"fp32" or "fp16" (see above); returns the previous setting."""
+    if name not in ("fp32", "fp16"):
+        raise ValueError("matrix path must be 'fp32' or 'fp16'")
+    prev = matrix_path()
+    _PREC[0] = 1 if name == "fp16" else 0
+    if prev != name:
+        _SPLITS_K.clear()    # the cached launch plans were made for the other kernels
+    return prev
+
+
 def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
-    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, 0, 1 if _DETERMINISTIC[0] else 0, 0, 0)
+    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, 0, 1 if _DETERMINISTIC[0] else 0, 0, 0, 0.0,
+                        _PREC[0] if H * W > 1 else 0)   # (linears - 1 x 1 maps - stay fp32: tiny, and the head's logits are built there)
 
 
 # Launch overrides for tools/step_autotune.py (tuning the launch table against the time of the WHOLE overlapped step instead of
@@ -586,8 +622,10 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
     # dgrad on cached transposed weights WT[Cin][KF][KF][Cout] (rows k-contiguous: the forward kernel's operand path, vector weight
     # loads) for the gradient w.r.t. IMAGES (<= 8 input
     # channels: 3 / 6 / 1), where the k-major kernel falls back to scalar weight loads (output channels not a multiple of 4)
-    if w is not None and Cout % 16 == 0 and not (ups and not fold) and Cin <= 8 and _NARROW_DGRAD_T:
-        J = _xfold_factor(Cin, W) if KH >= 3 and not (ups or pool or fold) and _NARROW_XFOLD else 0
+    # (fp16 matrix path: EVERY eligible dgrad goes this way - the fp16 kernel exists in the k-contiguous operand form only)
+    f16_t = sh.prec == 1 and Cout % 32 == 0 and Cin >= 32
+    if w is not None and Cout % 16 == 0 and not (ups and not fold) and ((Cin <= 8 and _NARROW_DGRAD_T) or f16_t):
+        J = _xfold_factor(Cin, W) if KH >= 3 and not (ups or pool or fold) and _NARROW_XFOLD and not f16_t else 0
         if J:   # J adjacent dx pixels as the output columns of one stride-(1, J) convolution: 12 of 16 MFMA columns carry data
             wx = _transposed(lib, w, wk, Cout, Cin, KH, xfold=J)
             dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)

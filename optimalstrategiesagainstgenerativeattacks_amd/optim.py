@@ -176,7 +176,9 @@ class FusedAdam(torch.optim.Optimizer):
             self._lr_cache = lrs
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=1.0):
+        """grad_scale multiplies the gradient bucket inside the Adam kernel (together with the 1 / world_size of the data-parallel
+        average): 1 / S after a backward pass of S * loss (the loss scale of the fp16 matrix path, ops.loss_scale)."""
         assert closure is None
         lib = _lib.load()
         self._ensure()
@@ -188,7 +190,7 @@ class FusedAdam(torch.optim.Optimizer):
             assert g["betas"] == g0["betas"] and g["eps"] == g0["eps"], "one (betas, eps) per optimizer"
         check(lib.gim_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
                                 self.flat_p.numel(), self._seg_end.data_ptr(), self._lr_dev.data_ptr(), len(self.param_groups),
-                                g0["betas"][0], g0["betas"][1], g0["eps"], scale, self._step_dev.data_ptr(),
+                                g0["betas"][0], g0["betas"][1], g0["eps"], scale * grad_scale, self._step_dev.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream), "adam_step")
         self.note_steps(1)
 

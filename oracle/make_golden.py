@@ -759,9 +759,12 @@ def main():
         gen_nets("tiny_m2", 16, 1, 32, 2, 2, 2, 1, torch.float64, full=False)
         gen_nets("tiny_att", 16, 1, 32, 2, 1, 3, 4, torch.float64, full=False, use_img_att=True)
     if "trainer" in which:
-        gen_trainer("reg0", 0.0)
+        # all three at the REAL learning rates of the path (train_gim_on_imgs.py defaults); round 4 moved reg0 / nau2 there too:
+        # at 2e-3 / 1e-3 Adam (beta1 = 0) moves every weight by ~lr per update, and the element samples of the second moments
+        # sat 14x above the reference's own fp32-vs-fp64 floor (3.3e-3 vs 2.4e-4, profiles/r04_trainer_fixture_fp32_noise.txt)
+        gen_trainer("reg0", 0.0, lrs=(1e-4, 1e-4, 1e-6))
         gen_trainer("reg10", 10.0, lrs=(1e-4, 1e-4, 1e-6))
-        gen_trainer("nau2", 0.0, n_steps=2, n_au_steps=2)
+        gen_trainer("nau2", 0.0, n_steps=2, n_au_steps=2, lrs=(1e-4, 1e-4, 1e-6))
     if "bench" in which:
         gen_nets("om32_f64", 32, 1, 512, 2, 1, 5, 10, torch.float64, full=False)
         gen_nets("om32_f32", 32, 1, 512, 2, 1, 5, 10, torch.float32, full=False)

@@ -346,11 +346,10 @@ def test_trainer_protocol_vs_reference_golden(tag):
         else:
             gres = G.im_eval_step(trainer, leaked, si, z=z)
         dres = G.au_train_step(trainer, real, gres[1], si)
-        # north_star: 1e-3 on losses / logits.  First iteration 1e-4; afterwards the north_star tolerance itself: at the learning
-        # rates of the reg0 / nau2 fixtures (2e-3 / 1e-3) every Adam(beta1 = 0) update moves each weight by ~lr whatever the
-        # gradient's size and rounding differences grow ~4x per iteration (measured 2e-4 on iteration 2).  The R1 fixture
-        # (round 3) runs at the path's real learning rates 1e-4 / 1e-4 / 1e-6, where the reference's own fp32 run stays within
-        # 3e-6 of its fp64 run through all iterations and the eval pass (profiles/r03_trainer_fixture_fp32_noise.txt): same bounds.
+        # north_star: 1e-3 on losses / logits.  First iteration 1e-4; afterwards the north_star tolerance itself.  All three
+        # fixtures run at the path's real learning rates 1e-4 / 1e-4 / 1e-6 (reg10 since round 3, reg0 / nau2 since round 4), where
+        # the reference's own fp32 run stays within 3e-6 of its fp64 run through all iterations and the eval pass
+        # (profiles/r04_trainer_fixture_fp32_noise.txt).
         tol = 1e-4 if it == 0 else 1e-3
         tol_fake = tol
         assert relerr(gres[0], g["it%d/g_loss" % it]) < tol, (it, "g_loss")
@@ -423,15 +422,21 @@ def test_trainer_protocol_vs_reference_golden(tag):
                 mine = opt.state[named[name]]["exp_avg_sq"].detach().double().reshape(-1)[::int(stride)].cpu().numpy()
                 ref = g[k_]
                 l2 = float(np.linalg.norm(mine - ref) / max(np.linalg.norm(ref), 1e-30))
-                # v = 0.01 g^2 summed over the iterations: twice the gradient's relative error.  The gradient bounds of _check_nets
-                # (3e-3, EnvDecoder 6e-3: its first blocks normalise 1x1 - 4x4 maps) give 6e-3 / 1.2e-2; measured
-                # 3.4e-3 on env_decoder.up_blocks.0.conv_r2 (run to run: the order of the float atomics), <= 1e-3 elsewhere
-                assert l2 < (1.2e-2 if name.startswith("env_decoder.") else 6e-3), ("Adam second moment sample", nm, name, l2)
+                # Bound = 3x the MEASURED floor of this fixture, at least 3e-4: the reference's own arithmetic in fp32 (the oracle in
+                # float32 on the CPU) against its fp64 run puts the worst tensor of these samples at 1.8e-5 (reg0), 9.1e-5 (reg10),
+                # 4.5e-4 (nau2) - profiles/r04_trainer_fixture_fp32_noise.txt.  (Round 3's bound here was 6e-3 / 1.2e-2, set after a
+                # red run: the reg0 / nau2 fixtures then ran at lr 2e-3 / 1e-3, where Adam with beta1 = 0 moves every weight by ~lr
+                # per update and the engine's trajectory left the fp64 one by 3.3e-3; round 4 regenerated them at the path's real
+                # learning rates, 1e-4 / 1e-4 / 1e-6, like reg10.)
+                assert l2 < max(3 * _ADAM_V_FP32_FLOOR[tag], 3e-4), ("Adam second moment sample", nm, name, l2)
                 worst_v.append((l2, nm, name))
                 n_checked += 1
     worst_v.sort(reverse=True)
     print("Adam second-moment samples, worst relative L2 per tensor: %s" % ", ".join("%.1e %s.%s" % w_ for w_ in worst_v[:4]))
     assert n_checked > 600, n_checked
+
+
+_ADAM_V_FP32_FLOOR = {"reg0": 1.8e-5, "reg10": 9.1e-5, "nau2": 4.5e-4}   # tools/trainer_fixture_fp32_noise.py, "worst Adam v L2"
 
 
 def _adam_step_off_shares(params, otr, lrs, beta2=0.99, noise_lr=1e-4):
