@@ -2202,12 +2202,9 @@ static WgPlan wgrad_plan(const gim_conv_shape* s) {
     // K step (~1.8 us), so short slices on many CUs win although they add more partial tiles (measured: tools/conv_autotune.py).
     // An explicit / table target lifts the 512-pixel floor to 64 (4 K-steps).
     long long minpix = 512;
-    if (f16 && !target) {
-        // the fp16 kernel's K loop is 8x shorter per pixel than the fp32 one's, its epilogue (128 x 128 float atomics per workgroup:
-        // 64 KB) is not: half the workgroups, slices of >= 1024 pixels, unless that leaves the chip idle
-        target = 512;
-        minpix = (tiles * ((M + 1023) / 1024) < 256) ? 256 : 1024;
-    } else if (!target) {
+    // (fp16 kernel: the same slicing - half as many, longer slices were measured 13 % slower over the config-5 step, 43.5 vs 49.8
+    //  episodes/s: the kernel is bound by operand traffic and wants the waves in flight, not fewer epilogues)
+    if (!target) {
         target = 1024;
         if (tiles * ((M + 511) / 512) < 256) minpix = 128;
     } else {

@@ -16,12 +16,12 @@ Q="--no-cpu-baseline --no-kernel-bench --no-traffic"
 timeout -k 10 300 python bench.py --workload om32 $Q > $out/bench_om32_B32.log 2>&1 || exit 1
 timeout -k 10 300 python bench.py --batch 64 $Q > $out/bench_vox64_B64.log 2>&1 || exit 1
 timeout -k 10 300 python bench.py --reg-param 10 $Q > $out/bench_vox64_B16_r1.log 2>&1 || exit 1
-timeout -k 10 300 python bench.py --graph $Q > $out/bench_vox64_B16_graph.log 2>&1 || exit 1
+timeout -k 10 300 python bench.py --workload vox128 --matrix-path fp16 $Q > $out/bench_vox128_B2_fp16.log 2>&1 || exit 1   # the opt-in 16-bit operand path (BASELINE config 5)
 GIM_NO_STEP_OVERLAP=1 timeout -k 10 300 python bench.py $Q > $out/bench_vox64_B16_eager_sequential.log 2>&1 || exit 1   # what the graph replays, launched eagerly
 timeout -k 10 300 python bench.py --workload vox128 $Q > $out/bench_vox128_B2.log 2>&1 || exit 1
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 GIM_FORCE_ALLREDUCE=1 timeout -k 10 300 python bench.py $Q > $out/bench_vox64_B16_rccl1rank.log 2>&1 || exit 1
 timeout -k 10 300 python bench.py $Q > $out/bench_vox64_B16_again.log 2>&1 || exit 1   # box drift check: the default again, after the sustained load above
-for f in om32_B32 vox64_B64 vox64_B16_r1 vox64_B16_graph vox64_B16_eager_sequential vox128_B2 vox64_B16_rccl1rank vox64_B16_again; do echo "$f: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$f.log | head -1)"; done
+for f in om32_B32 vox64_B64 vox64_B16_r1 vox128_B2_fp16 vox64_B16_eager_sequential vox128_B2 vox64_B16_rccl1rank vox64_B16_again; do echo "$f: $(grep -o '"value": [0-9.]*, "unit"' $out/bench_$f.log | head -1)"; done
 timeout -k 10 300 python tools/conv_shapes_bench.py > $out/conv_shapes_fp32.txt 2>&1 || exit 1
 tail -1 $out/conv_shapes_fp32.txt
 cd /tmp && export TMPDIR=/tmp
