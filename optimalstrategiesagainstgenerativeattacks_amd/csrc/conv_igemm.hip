@@ -889,197 +889,6 @@ __global__ __launch_bounds__(256, TM * TN <= 2 ? 3 : 2) void conv_igemm_patch_ke
 }
 
 // -------------------------------------------------------------------------------------------------
-// Patch-resident form for the pool-folded forward (geometry S2: stride-2 gather over the 4 x 4 folded taps of a 3x3 conv, see the top
-// of this file).  A tile of 64 consecutive pooled pixels (R rows x Wt columns) reads (2 R + 2) x (2 Wt + 2) input pixels for all 16
-// taps: loaded once per 16-channel chunk instead of once per tap (2.6-4x fewer activation loads, LDS writes and LeakyReLUs; no
-// per-row address work in the K loop).  The patch is stored with even and odd input columns de-interleaved,
-// [row][column parity][column / 2][k], so that the 32 consecutive output pixels of a fragment read stay on consecutive LDS rows
-// (conflict-free ds_read_b128): tap (ta, tb) of tile pixel (ty, tx) is row 2 ty + ta, parity tb & 1, position tx + (tb >> 1).
-// ONE patch buffer (up to 396 pixels = 32 KB): the next chunk's patch waits in registers and is written behind a second barrier
-// in the chunk's last K step.  BMODE 0 weights (folded, k-contiguous rows), 64-row tiles, pooled maps of 64 ... 32 x 32 pixels rows.
-// Host guarantees: geometry S2 with 4 x 4 taps, Ca % 16 == 0, pooled H * W >= 64, pooled W <= 32, split-K in whole chunks.
-// -------------------------------------------------------------------------------------------------
-template <int BN, int TN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_patch_s2_kernel(const ConvP p) {
-    constexpr int BM = 64, TM = 1, KB = 16, LDK = KB + 4, T = 4;
-    constexpr int WAVES_N = BN / (32 * TN), WAVES_M = BM / (32 * TM);
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    constexpr int P_PER = 7;                         // patch quads per thread: (2 R + 2) * (2 Wt + 2) <= 396 pixels
-    constexpr int B_ROWS = BN / 64;
-    constexpr int B_SZ = BN * LDK;
-    extern __shared__ __attribute__((aligned(16))) float patch_lds[];
-    const Geo& g = p.g;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int kslice = blockIdx.z;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int Wt = min(g.W, BM), logWt = 31 - __builtin_clz(Wt), R = BM / Wt;
-    const int cols = 2 * Wt + 2, rows = 2 * R + 2, PP = rows * cols;
-    const int PWh = Wt + 1;                          // positions per column-parity plane
-    const int RS = 2 * PWh * LDK;                    // floats per patch row (two planes)
-    const int P_SZ = rows * RS;
-    float* Ps = patch_lds;
-    float* Bs = patch_lds + P_SZ;
-    const int n_img = m0 >> (g.logH + g.logW);
-    const int iy0 = 2 * ((m0 >> g.logW) & (g.H - 1)) + g.off_y, ix0 = 2 * (m0 & (g.W - 1)) + g.off_x;
-    const int KF2 = g.KF * g.KFw;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xFFFFFFFFu, 0x00020000);
-    unsigned p_voff[P_PER];
-    int p_lds[P_PER];
-#pragma unroll
-    for (int i = 0; i < P_PER; ++i) {
-        const int q = t + 256 * i, pp = q >> 2, quad = q & 3;
-        const int pr = pp / cols, pc = pp - pr * cols;
-        const int iy = iy0 + pr, ix = ix0 + pc;
-        const bool v = pp < PP && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
-        p_voff[i] = v ? (unsigned)((((n_img * g.Hin + iy) * g.Win + ix) * p.Ca + quad * 4) * 4) : BUF_OOB;
-        p_lds[i] = pp < PP ? pr * RS + ((pc & 1) * PWh + (pc >> 1)) * LDK + quad * 4 : -1;
-    }
-    unsigned b_voff[B_ROWS];
-    const int brow = t >> 2, bq = (t & 3) * 4;
-#pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) b_voff[i] = (unsigned)((min(n0 + brow + 64 * i, p.Cb - 1) * KF2 * p.Cin_w + bq) * 4);
-    const bool has_act = p.pre_slope != 1.0f;
-    f32x4 rp[P_PER], rb[B_ROWS];
-    auto load_patch = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < P_PER; ++i) rp[i] = buf_load4(rx, p_voff[i], (unsigned)(c0 * 4));
-    };
-    auto store_patch = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < P_PER; ++i) {
-            if (has_act) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rp[i][e] = __builtin_amdgcn_fmed3f(rp[i][e], rp[i][e] * p.pre_slope, p.pos_inf);
-            }
-            if (p_lds[i] >= 0) *reinterpret_cast<f32x4*>(&Ps[p_lds[i]]) = rp[i];
-        }
-    };
-    auto load_b = [&](int ta, int tb, int c0) __attribute__((always_inline)) {
-        const int wtap = (g.wa_base + g.wa_step * ta) * g.KFw + g.wb_base + g.wb_step * tb;
-        const unsigned sb = (unsigned)((wtap * p.Cin_w + c0) * 4);
-#pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_voff[i], sb);
-    };
-    auto store_b = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + (brow + 64 * i) * LDK + bq]) = rb[i];
-    };
-    const int r = lane & 31, h = lane >> 5;
-    const int wm0 = (wv / WAVES_N) * 32 * TM, wn0 = (wv % WAVES_N) * 32 * TN;
-    // A fragment bases: one per (tap row, column parity); tb >> 1 and the k quad are immediates
-    int a_base[T][2];
-    {
-        const int q = wm0 + r, ty = q >> logWt, tx = q & (Wt - 1);
-#pragma unroll
-        for (int ta = 0; ta < T; ++ta)
-#pragma unroll
-            for (int par = 0; par < 2; ++par) a_base[ta][par] = (2 * ty + ta) * RS + (par * PWh + tx) * LDK + 4 * h;
-    }
-    f32x16 acc[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    const int nchunk = p.Ca / KB;
-    const int ch0 = kslice * (p.kper / (T * T));
-    const int ch1 = min(nchunk, ch0 + p.kper / (T * T));
-    load_patch(ch0 * KB);
-    load_b(0, 0, ch0 * KB);
-    store_patch();
-    store_b(0);
-    __syncthreads();
-    auto kstep = [&](int ch, bool more_chunks, auto TAPC) __attribute__((always_inline)) {
-        constexpr int TAP = decltype(TAPC)::value, BB = TAP & 1;
-        constexpr int TA = TAP / T, TB = TAP % T, LAST = T * T - 1;
-        if (TAP == 0 && more_chunks) load_patch((ch + 1) * KB);
-        if (TAP < LAST) load_b((TAP + 1) / T, (TAP + 1) % T, ch * KB);
-        else if (more_chunks) load_b(0, 0, (ch + 1) * KB);
-        __builtin_amdgcn_sched_barrier(0);
-        const float* Bb = Bs + BB * B_SZ;
-        f32x4 a[2], b[2][TN];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            a[kk] = *reinterpret_cast<const f32x4*>(&Ps[a_base[TA][TB & 1] + (TB >> 1) * LDK + 8 * kk]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[kk][j] = *reinterpret_cast<const f32x4*>(&Bb[(wn0 + 32 * j + r) * LDK + 8 * kk + 4 * h]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][e], b[kk][j][e], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (TAP < LAST) {
-            store_b(BB ^ 1);
-        } else if (more_chunks) {
-            __syncthreads();          // every wave has read the patch of this chunk
-            store_b(BB ^ 1);
-            store_patch();
-        }
-        __syncthreads();
-    };
-    for (int ch = ch0; ch < ch1; ++ch) {   // 16 taps: the weight buffer parity is back at 0 after every chunk
-        const bool more_chunks = ch + 1 < ch1;
-        kstep(ch, more_chunks, std::integral_constant<int, 0>());
-        kstep(ch, more_chunks, std::integral_constant<int, 1>());
-        kstep(ch, more_chunks, std::integral_constant<int, 2>());
-        kstep(ch, more_chunks, std::integral_constant<int, 3>());
-        kstep(ch, more_chunks, std::integral_constant<int, 4>());
-        kstep(ch, more_chunks, std::integral_constant<int, 5>());
-        kstep(ch, more_chunks, std::integral_constant<int, 6>());
-        kstep(ch, more_chunks, std::integral_constant<int, 7>());
-        kstep(ch, more_chunks, std::integral_constant<int, 8>());
-        kstep(ch, more_chunks, std::integral_constant<int, 9>());
-        kstep(ch, more_chunks, std::integral_constant<int, 10>());
-        kstep(ch, more_chunks, std::integral_constant<int, 11>());
-        kstep(ch, more_chunks, std::integral_constant<int, 12>());
-        kstep(ch, more_chunks, std::integral_constant<int, 13>());
-        kstep(ch, more_chunks, std::integral_constant<int, 14>());
-        kstep(ch, more_chunks, std::integral_constant<int, 15>());
-    }
-
-    EpiCtx ec;
-    ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
-    ec.mask_slope = p.mask_slope;
-    ec.post_slope = p.post_slope;
-    const bool first = kslice == 0;
-    const bool has_res = p.res != nullptr && first, has_mask = p.mask_x != nullptr;
-    ec.atom = p.ksplit > 1;
-    ec.remap = false;
-    ec.M = p.M; ec.Cb = p.Cb;
-    ec.logH = g.logH; ec.logW = g.logW; ec.Hm1 = g.H - 1; ec.Wm1 = g.W - 1; ec.os = 1; ec.py = 0; ec.px = 0;
-    ec.Ho = g.H; ec.Wo = g.W;
-    const unsigned ybytes = (unsigned)g.N * (unsigned)g.H * (unsigned)g.W * (unsigned)p.Cb * 4u;
-    ec.ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
-    ec.rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, has_res ? (p.res_ups ? ybytes >> 2 : ybytes) : 0u, 0x00020000);
-    ec.rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_x, 0, has_mask ? ybytes : 0u, 0x00020000);
-    auto run = [&](auto MODEC) {
-        constexpr int MODE = decltype(MODEC)::value;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn0 + 32 * j + r;
-            const bool cok = co < p.Cb;
-            const float bv = (p.bias && first && cok) ? p.bias[co] : 0.f;
-            float a[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) a[e] = acc[j][e];
-            epi_block<16, MODE>(ec, a, m0 + wm0 + 4 * h, co, cok, bv);
-        }
-    };
-    if (has_res) {
-        if (p.res_ups) run(std::integral_constant<int, 2>());
-        else run(std::integral_constant<int, 1>());
-    } else if (has_mask) {
-        run(std::integral_constant<int, 3>());
-    } else {
-        run(std::integral_constant<int, 0>());
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
 // wgrad
 // -------------------------------------------------------------------------------------------------
 struct WgP {
@@ -1883,43 +1692,6 @@ static bool launch_patch(const ConvP& p, size_t y_elems, hipStream_t st, int wan
     return true;
 }
 
-// Patch-resident launch of a pool-folded 3x3 forward (conv_igemm_patch_s2_kernel): 64-row tiles, 4 x 4 taps.
-template <int BN, int TN>
-static void launch_patch_s2_cfg(ConvP p, size_t y_elems, hipStream_t st, bool table_hit) {
-    const int gx = (p.M + 63) / 64, gy = (p.Cb + BN - 1) / BN;
-    const int chunks = p.Ca / 16, T2 = 16;
-    int ks = plan_ksplit((long long)gx * gy, chunks * T2, 64 * BN, p.tune_ks);
-    if (ks > chunks) ks = chunks;
-    const int cps = (chunks + ks - 1) / ks;
-    p.ksplit = (chunks + cps - 1) / cps;
-    p.kper = cps * T2;
-    if (t_plan_out) {
-        const int32_t v[8] = {table_hit ? 1 : 0, 64, BN, p.ksplit, gx, gy, p.ksplit, 1};
-        for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
-        return;
-    }
-    if (p.ksplit > 1 && p.post_slope != 1.f) {
-        gim_set_error("conv fwd: post_slope with a launch that splits K (ask gim_conv_launch_plan first)");
-        t_launch_refused = true;
-        return;
-    }
-    if (p.ksplit > 1 && !p.y_zeroed) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
-    const int Wt = p.g.W < 64 ? p.g.W : 64;
-    const int rows = 2 * (64 / Wt) + 2;
-    const size_t lds = (size_t)(rows * 2 * (Wt + 1) * 20 + 2 * BN * 20) * sizeof(float);
-    hipLaunchKernelGGL((conv_igemm_patch_s2_kernel<BN, TN>), dim3(gx, gy, p.ksplit), dim3(256), lds, st, p);
-}
-
-static bool launch_patch_s2(const ConvP& p, size_t y_elems, hipStream_t st, int want, bool table_hit) {
-    const Geo& g = p.g;
-    if (g.pc || g.ups || g.s_in != 2 || g.s_in_x != 2 || g.os != 1 || g.Th != 4 || g.Tw != 4) return false;
-    if (p.Ca % 16 != 0 || p.Cb < 32 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return false;
-    if (g.H * g.W < 64 || g.W > 32) return false;
-    if (want == 641 && p.Cb > 64) launch_patch_s2_cfg<128, 2>(p, y_elems, st, table_hit);
-    else launch_patch_s2_cfg<64, 1>(p, y_elems, st, table_hit);
-    return true;
-}
-
 // fp16-operand launch (conv_igemm_f16_kernel): K steps of 32, tile by shape - the kernel is bound by operand traffic, so the largest
 // tile that still fills the chip; split-K as for the fp32 kernels.  No table rows (the table was measured on the fp32 kernels).
 template <int BM, int BN, int TM, int TN>
@@ -1979,9 +1751,6 @@ static void launch_igemm(const ConvP& p, size_t y_elems, hipStream_t st) {
     if (patch_row) want -= 20000;
     if constexpr (GEN == 0) {
         if ((patch_row || (!te && p.tune_tile == 0 && p.tune_ks == 0)) && launch_patch<BMODE>(pt, y_elems, st, want, hit)) return;
-        if constexpr (BMODE == 0) {   // pool-folded forward: on request only (tile code + 20000), 64-row tiles
-            if (patch_row && launch_patch_s2(pt, y_elems, st, want, hit)) return;
-        }
     }
     if (Cb > 64) {
         const long long t128 = (long long)((M + 127) / 128) * ((Cb + 127) / 128) * (p.g.pc ? 4 : 1);

@@ -142,37 +142,6 @@ def test_conv2d_pool_fold(case):
         assert relerr(nchw(rg.grad), res.grad) < TOL, "dres"
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,tile,ks", [(5, 64, 64, 64, 20064, 0), (3, 128, 128, 32, 20641, 0), (4, 32, 96, 16, 20064, 2), (2, 16, 160, 32, 20641, 1),
-                                                  (9, 256, 64, 16, 20064, 4)])
-def test_pool_fold_forward_patch_resident_loop(N, Cin, Cout, H, tile, ks):
-    """avgpool2(conv3x3(lrelu(x))) + bias + residual as the stride-2 folded convolution, PATCH-RESIDENT loop (tile code + 20000: the
-    (2 rows + 2) x (2 columns + 2) input patch of a 64-pixel tile stays in LDS for all 16 taps) against fp64 autograd's forward, with
-    1 / sigma, with and without split K, pooled maps of 8 ... 32 pixels per row, ragged output channels."""
-    from optimalstrategiesagainstgenerativeattacks_amd import _lib
-    import ctypes
-    lib = _lib.load()
-    g = torch.Generator(device="cuda").manual_seed(21)
-    x = torch.randn(N, H, H, Cin, device=dev(), generator=g)
-    w = torch.randn(Cout, 3, 3, Cin, device=dev(), generator=g) / np.sqrt(9 * Cin)
-    b = torch.randn(Cout, device=dev(), generator=g)
-    res = torch.randn(N, H // 2, H // 2, Cout, device=dev(), generator=g)
-    sigma = torch.tensor([1.3], device=dev())
-    st = torch.cuda.current_stream().cuda_stream
-    f = torch.empty(Cout * 16 * Cin, device=dev())
-    _lib.check(lib.gim_conv2d_fold_weights(w.data_ptr(), f.data_ptr(), Cout, Cin, 3, st), "fold_weights")
-    sh = _lib.GimConvShape(N, H, H, Cin, Cout, 3, 0, 0.2, 1, 1, 0, tile, ks, 0)
-    plan = (ctypes.c_int32 * 8)()
-    lib.gim_conv_launch_plan(sh, 0, ctypes.cast(plan, ctypes.c_void_p))
-    assert plan[7] == 1 and plan[1] == 64, list(plan)       # the patch-resident kernel, 64-row tile
-    assert ks == 0 or plan[3] == ks, list(plan)
-    y = torch.full((N, H // 2, H // 2, Cout), float("nan"), device=dev())
-    _lib.check(lib.gim_conv2d_fwd(x.data_ptr(), f.data_ptr(), b.data_ptr(), sigma.data_ptr(), res.data_ptr(), y.data_ptr(), sh, st), "fwd")
-    xr = x.double().permute(0, 3, 1, 2)
-    ref = F.avg_pool2d(F.conv2d(F.leaky_relu(xr, 0.2), w.double().permute(0, 3, 1, 2) / 1.3, padding=1), 2) + b.double().view(1, -1, 1, 1) \
-        + res.double().permute(0, 3, 1, 2)
-    assert relerr(y.permute(0, 3, 1, 2).double(), ref) < TOL
-
-
 @pytest.mark.parametrize("N,C1,C2,H,expect_act", [(6, 16, 64, 32, True), (2, 64, 64, 4, False)])
 def test_conv_pair_with_activated_storage(N, C1, C2, H, expect_act):
     """conv_r1 -> LeakyReLU -> pooled conv_r2 (models/model_blocks.py:505-510) with the intermediate stored ACTIVATED by conv_r1's

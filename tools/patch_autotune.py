@@ -33,36 +33,7 @@ def main():
     lines, tot_a, tot_b = [], 0.0, 0.0
     for cfg, cnt in sorted(fwd.items(), key=lambda kv: -kv[1]):
         N, H, W, Cin, Cout, KH, ups, slope, pool, fold = cfg
-        if KH == 3 and pool and fold and not ups and Cin % 16 == 0 and Cout >= 32 and (H // 2) * (W // 2) >= 64 and W // 2 <= 32 and "pool" in args.kinds:
-            # pool-folded forward: conv_igemm_patch_s2_kernel (64-row tiles)
-            x = torch.randn(N, H, W, Cin, device=dev)
-            f = torch.randn(Cout, 4, 4, Cin, device=dev) * 0.05
-            y = torch.empty(N, H // 2, W // 2, Cout, device=dev)
-
-            def pshape(tile=0, ks=0):
-                return _lib.GimConvShape(N, H, W, Cin, Cout, 3, 0, slope, 1, 1, 0, tile, ks, 0)
-            fn = lambda s_: lib.gim_conv2d_fwd(x.data_ptr(), f.data_ptr(), None, None, None, y.data_ptr(), s_, st)   # noqa: E731
-            plan = (ctypes.c_int32 * 8)()
-            lib.gim_conv_launch_plan(pshape(), 0, ctypes.cast(plan, ctypes.c_void_p))
-            tcode, tks = CODE.get((plan[1], plan[2]), 64), plan[3]
-            t_tap = min(time_ms(lambda: fn(pshape(tcode, tks))) for _ in range(3))
-            best = (1e9, 0, 0)
-            for tl in ([64, 641] if Cout > 64 else [64]):
-                for ks in (1, 2, 3, 4, 6, 8):
-                    t = time_ms(lambda: fn(pshape(tl + 20000, ks)), reps=10)
-                    if t < best[0]:
-                        best = (t, tl, ks)
-            t_patch = min(best[0], time_ms(lambda: fn(pshape(best[1] + 20000, best[2]))))
-            use_patch = t_patch < t_tap * 0.98
-            tot_a += cnt * t_tap
-            tot_b += cnt * (t_patch if use_patch else t_tap)
-            print("fwd   %-30s x%-2d tap-major (tile %d, ks %d) %.3f ms | patch-resident best (tile %d, ks %d) %.3f ms  %+.1f %%  [pool fold]"
-                  % (",".join(str(c) for c in cfg[:6]), cnt, tcode, tks, t_tap, best[1], best[2], t_patch, 100 * (t_tap / t_patch - 1)), flush=True)
-            if use_patch:
-                lib.gim_conv_launch_plan(pshape(best[1] + 20000, best[2]), 0, ctypes.cast(plan, ctypes.c_void_p))
-                lines.append("    {0, %d, %d, %d, %d, 0, %d, %d},  // fwd %s: patch-resident %.3f ms (tap-major %.3f, patch-resident %.3f)"
-                             % (N * (H // 2) * (W // 2), Cin, Cout, 16 * Cin, CODE[(plan[1], plan[2])] + 20000, plan[3], ",".join(str(c) for c in cfg), t_patch, t_tap, t_patch))
-            continue
+        # (the pool-folded forward's patch-resident kernel was removed in round 4: profiles/r03_l_patch_resident_pool_fold.txt)
         if KH != 3 or ups or pool or fold or Cin % 16 or Cout % 16 or H * W < 64:
             continue
         n_dx = sum(c for (cf, dx, dw), c in bwd.items() if cf == cfg and dx)
