@@ -53,3 +53,13 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// conv_tiny.hip: direct convolution of the 3 -> 3 / 1 -> 1 image layers (3x3, 9x9; plain geometry).  Each returns false when the
+// shape is not one of them (the implicit-GEMM kernels run); plan_out != nullptr: record the launch plan, launch nothing.
+bool gim_tiny_shape(const gim_conv_shape* s);
+bool gim_tiny_fwd(const float* x, const float* w, const float* bias, const float* sigma, const float* res, float* y,
+                  const gim_conv_shape* s, hipStream_t st, int32_t* plan_out);
+bool gim_tiny_dgrad(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx, const gim_conv_shape* s,
+                    hipStream_t st, int32_t* plan_out);
+bool gim_tiny_wgrad_acc(const float* dy, const float* x, float* acc, float* bias_acc, const gim_conv_shape* s, hipStream_t st,
+                        int32_t* plan_out);

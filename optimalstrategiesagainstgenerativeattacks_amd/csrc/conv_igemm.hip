@@ -1775,6 +1775,9 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(x && w && y, "conv fwd: null pointer");
+    // 3 -> 3 / 1 -> 1 image layers: direct convolution (conv_tiny.hip) unless the caller chose a launch (tune_* / deterministic mode)
+    if (s->tune_tile == 0 && s->tune_ksplit == 0 && gim_tiny_fwd(x, w, bias, sigma, residual, y, s, (hipStream_t)stream, t_plan_out))
+        return t_plan_out ? GIM_OK : gim_check_launch("gim_conv2d_fwd");
     {   // operands beyond the 32-bit buffer-offset range: halve the batch (images are independent)
         const size_t xi = (size_t)(s->H >> s->ups) * (s->W >> s->ups) * s->Cin;        // elements per image
         const size_t yi = (size_t)(s->H >> s->pool) * (s->W >> s->pool) * s->Cout;
@@ -1822,6 +1825,8 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
     int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(dy && w && dx, "conv dgrad: null pointer");
+    if (!transposed && s->tune_tile == 0 && s->tune_ksplit == 0 && gim_tiny_dgrad(dy, w, sigma, mask_x, dx, s, (hipStream_t)stream, t_plan_out))
+        return t_plan_out ? GIM_OK : gim_check_launch("gim_conv2d_dgrad");
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(mask_x && s->ups && !up_fold), "conv dgrad: mask_x with ups == 1 needs folded weights");
     {
@@ -2134,6 +2139,15 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     if (atomic && !prezeroed && !t_plan_out) {
         (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
         if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
+    }
+    // 3 -> 3 / 1 -> 1 image layers, slices combined by atomics: the direct kernel (conv_tiny.hip)
+    if ((prezeroed || n_slabs == 1) && s->tune_tile == 0 && s->tune_wgrad == 0 && gim_tiny_shape(s)) {
+        if (!prezeroed && !atomic && !t_plan_out) {   // (atomic: the memsets above have run)
+            (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
+            if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
+        }
+        (void)gim_tiny_wgrad_acc(dy, x, slabs, bias_slabs, s, (hipStream_t)stream, t_plan_out);
+        return t_plan_out ? GIM_OK : gim_check_launch("gim_conv2d_wgrad");
     }
     // plain 3x3, row-resident kernel: on request (tile code >= 20000 from the caller or the table row; ks / target = workgroups wanted)
     // (W >= 4: the narrowest instantiation walks rows of 4 pixels - a non-square 8 x 2 map passes H * W >= 16 and must not run it)

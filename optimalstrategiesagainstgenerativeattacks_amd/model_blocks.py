@@ -325,6 +325,9 @@ class ResBlockDown(nn.Module):
         gap between the other waves' MFMAs, profiles/r03_a_igemm_loop_lab.txt), reads it as it is, and the skip path - which
         needs the RAW x - inverts the activation inside its pooling kernel (LeakyReLU is a bijection).  post_slope != 1 asks for
         the block OUTPUT in activated form in turn; y_act says whether it is (a launch that splits K cannot activate)."""
+        # (Round 4 tried the skip path - pool + 1x1 conv, two launches of 5-17 us - on a side stream of the lane, under conv_r1 instead of
+        #  in front of it: 295-297 against 418-420 episodes/s.  One more stream per lane couples the two encoder streams that share
+        #  it and adds two cross-queue waits per block and direction; profiles/r04_e_skip_stream_rejected.txt.)
         x, pooled = ops.fork_pool(x, LRELU if x_act else 1.0)   # the two consumers of x; their gradients meet in one kernel
         left = self.conv_l1(pooled)
         # conv_r2 is the only reader of conv_r1's output and applies LeakyReLU to it: conv_r1 stores it activated (once per element

@@ -108,6 +108,63 @@ def test_conv2d_fwd_bwd(case):
         assert relerr(nchw(rg.grad), res.grad) < TOL, "dres"
 
 
+TINY_CASES = [
+    # N, C, K, H, W, slope, res (0 none, 1 full resolution, 2 half resolution), x stored activated
+    (3, 3, 9, 64, 64, 0.2, 2, True),     # the generator's last 9x9 conv as the model calls it (models/gim_img_models.py:187-193)
+    (2, 3, 3, 32, 32, 0.2, 2, True),     # the decoder's last 3x3 conv (models/gim_img_models.py:128)
+    (2, 3, 9, 8, 8, 0.2, 1, False),      # a map smaller than the 16 x 16 tile
+    (5, 3, 3, 16, 32, 1.0, 0, False),    # non-square, no activation
+    (2, 1, 9, 32, 32, 0.2, 2, False),    # one-channel data (32x32x1 workload)
+    (3, 1, 3, 4, 4, 0.2, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", TINY_CASES, ids=[str(c) for c in TINY_CASES])
+def test_tiny_image_conv_direct_kernels(case):
+    """3 -> 3 / 1 -> 1 image layers run the direct kernels of conv_tiny.hip (launch plan: loop form 3) - forward with bias, 1/sigma and
+    a full- or half-resolution residual, the masked input gradient, weight and bias gradients - against fp64 F.conv2d autograd."""
+    import ctypes
+    from optimalstrategiesagainstgenerativeattacks_amd import _lib, ops
+    N, C, K, H, W, slope, res_kind, x_act = case
+    tag = "tiny%s" % (case,)
+    x = T(pf.normal(tag + "x", (N, C, H, W))).requires_grad_()
+    w = T(pf.normal(tag + "w", (C, C, K, K)) / np.sqrt(C * K * K)).requires_grad_()
+    b = T(pf.normal(tag + "b", (C,))).requires_grad_()
+    res = None
+    if res_kind == 1:
+        res = T(pf.normal(tag + "r", (N, C, H, W))).requires_grad_()
+    elif res_kind == 2:
+        res = T(pf.normal(tag + "r", (N, C, H // 2, W // 2))).requires_grad_()
+    sig = 1.3
+    xa = F.leaky_relu(x, slope) if slope != 1.0 else x
+    y = F.conv2d(xa, w / sig, b, padding=(K - 1) // 2)
+    if res is not None:
+        y = y + (go.upsample2(res) if res_kind == 2 else res)
+    r = T(pf.uniform(tag + "dy", tuple(y.shape)))
+    (y * r).sum().backward()
+    sh = ops._shape(N, H, W, C, C, K, 0, slope)
+    for kind in (0, 1, 3):
+        out = (ctypes.c_int32 * 8)()
+        _lib.check(_lib.load().gim_conv_launch_plan(ctypes.byref(sh), kind, ctypes.cast(out, ctypes.c_void_p)), "plan")
+        assert out[7] == 3, ("not the direct kernel", kind, list(out))
+    # the model stores this conv's input ACTIVATED (its producer applied the LeakyReLU): feed lrelu(x) with x_act=True then
+    xin = nhwc(F.leaky_relu(x, slope) if x_act else x).requires_grad_()
+    wg = cl_weight(w)
+    bg = b.detach().float().to(dev()).requires_grad_()
+    rg = nhwc(res).requires_grad_() if res is not None else None
+    sg = torch.tensor([sig], device=dev())
+    u0, v0 = torch.zeros(C, device=dev()), torch.zeros(C * K * K, device=dev())
+    yg = ops.conv2d(xin, wg, bg, rg, sg, u0, v0, 0, slope, False, res_kind == 2, None, None, x_act)
+    assert relerr(nchw(yg), y) < TOL, "forward"
+    (yg * nhwc(r)).sum().backward()
+    # gradient w.r.t. the RAW x either way (an activated input hands back the raw gradient: ops.ConvFn)
+    assert relerr(nchw(xin.grad), x.grad) < TOL, "dx"
+    assert relerr(wg.grad.double().cpu(), w.grad) < TOL, "dw"
+    assert relerr(bg.grad.double().cpu(), b.grad) < TOL, "db"
+    if res is not None:
+        assert relerr(nchw(rg.grad), res.grad) < TOL, "dres"
+
+
 @pytest.mark.parametrize("case", POOL_CASES, ids=[str(c) for c in POOL_CASES])
 def test_conv2d_pool_fold(case):
     """avgpool2(conv(lrelu(x))) + res as ONE stride-2 convolution with folded weights: fwd, dx, dw, db, dres."""
