@@ -168,6 +168,22 @@ int gim_conv2d_xfold_weights(const float* w, float* wx, int Cout, int Cin, int K
 int gim_conv2d_dgrad_xfold(const float* dy, const float* wx, const float* sigma, const float* mask_x, float* dx,
                            const gim_conv_shape* shape, int J, void* stream);
 
+/* Row-contiguous form of the image layers (<= 8 input channels, plain stride-1 convolution, KH * Cin <= 64, >= 16 output channels):
+ * in NHWC memory the KH taps of one tap ROW of an output pixel are KH * Cin contiguous floats, so on a zero-padded copy of the image
+ * the convolution is an implicit GEMM over KH "taps" of CaP = KH * Cin rounded up to 16 "channels" with a pixel stride of Cin floats -
+ * 16-byte vector loads where the generic path gathers scalars (the first conv of every encoder, models/gim_img_models.py:30-36 ->
+ * models/model_blocks.py:493,505; the 9x9 6 -> 64 conv of the image-to-image module, models/gim_img_models.py:123).
+ *   gim_pad_image: xp [N, H + 2 pad, W + 2 pad, C] = lrelu(x, slope) with a zero border (the conv's LeakyReLU is applied here, once).
+ *   gim_conv2d_pack_rows_weights: wp [Cout][KH][CaP] = the rows of w [Cout][KH][KH][Cin], zero-padded.
+ *   gim_conv2d_fwd_rows: y = conv / sigma + bias + residual (+ post_slope) from xp and wp; shape = the convolution's own shape.
+ *   gim_conv2d_wgrad_rows_acc: dW slot [Cout][KH][CaP] += dy^T * rows(xp), bias slot += column sums of dy (pre-zeroed slots, float
+ *     atomics); gim_wgrad_finish_batched un-pads the slot with gim_wgrad_job.fold = 3. */
+int gim_pad_image(const float* x, float* xp, int N, int H, int W, int C, int pad, float slope, void* stream);
+int gim_conv2d_pack_rows_weights(const float* w, float* wp, int Cout, int Cin, int KH, void* stream);
+int gim_conv2d_fwd_rows(const float* xp, const float* wp, const float* bias, const float* sigma, const float* residual,
+                        float* y, const gim_conv_shape* shape, void* stream);
+int gim_conv2d_wgrad_rows_acc(const float* dy, const float* xp, float* acc, float* bias_acc, const gim_conv_shape* shape, void* stream);
+
 /* Introspection (tests, tools/conv_autotune.py): the launch an entry point would make for `shape`, nothing is launched.
  *   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
  *   out[8] = {1 if a row of the compiled-in per-shape launch table matched, tile rows, tile columns, split-K factor

@@ -88,6 +88,10 @@ SIGNATURES = {
     "gim_img_att_mix_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, P],
     "gim_adam_step": [P, P, P, P, c_int64, P, P, c_int, c_float, c_float, c_float, c_float, P, P],
     "gim_spin": [c_int, P],
+    "gim_pad_image": [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P],
+    "gim_conv2d_pack_rows_weights": [P, P, c_int, c_int, c_int, P],
+    "gim_conv2d_fwd_rows": [P, P, P, P, P, P, SP, P],
+    "gim_conv2d_wgrad_rows_acc": [P, P, P, P, SP, P],
     "gim_version": [],
 }
 

@@ -95,6 +95,8 @@ struct ConvP {
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
     int kper;     // K-steps per slice
+    int pix;      // floats between consecutive PIXELS of the gathered tensor: = Ca, except in the row-contiguous form of the <= 8-channel
+                  // image layers (gim_conv2d_fwd_rows: Ca = the padded length of one tap ROW, K * Cin rounded up to 16, pix = Cin)
     int f16;      // host only: gim_conv_shape.prec == 1 - fp16 operands on v_mfma_f32_32x32x16_f16 where the launch is eligible (conv_f16.inc)
 };
 
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
             const int n = m >> (g.logH + g.logW);
             a_oy[i] = ((m >> g.logW) & (g.H - 1)) * g.s_in + g.off_y;
             a_ox[i] = (m & (g.W - 1)) * g.s_in_x + g.off_x;
-            a_base[i] = (unsigned)((n * g.Hin * g.Win * p.Ca + aq) * 4);
+            a_base[i] = (unsigned)((n * g.Hin * g.Win * p.pix + aq) * 4);
             a_cur[i] = BUF_OOB;
         }
         if constexpr (BMODE == 0) {
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
             const int iy = a_oy[i] + ta, ix = a_ox[i] + tb;
             const bool v = (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
             const int py = g.ups ? (iy >> 1) : iy, px = g.ups ? (ix >> 1) : ix;
-            a_cur[i] = v ? a_base[i] + (unsigned)((py * g.Win + px) * p.Ca * 4) : BUF_OOB;
+            a_cur[i] = v ? a_base[i] + (unsigned)((py * g.Win + px) * p.pix * 4) : BUF_OOB;
         }
     };
 
@@ -909,6 +911,8 @@ struct WgP {
     int atomic;        // 1: all pixel slices add into ONE pre-zeroed slab with float atomics (no reduce pass)
     int ns;            // pixel slices
     int xcd;           // 1: XCD-aware block order (the grid's z extent is then ns rounded up to a multiple of 8, see wgrad_block)
+    int pix;           // floats between consecutive pixels of x: = Cin, except in the row-contiguous form (gim_conv2d_wgrad_rows_acc:
+                       // "Cin" = padded tap-row length, pix = the image's channel count)
 };
 
 // Block -> (column tile, row tile, pixel slice), XCD-aware.  Every tile of one pixel slice streams the SAME dY rows and x rows
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgP p) {
     unsigned a_v[A_PER], b_l[B_PER];
     int b_dx[B_PER], b_dy[B_PER];
     // the most negative lane constant is shifted into the base pointer so that every offset is a non-negative 32-bit value
-    const int b_bias = ((g.off_y < 0 ? -g.off_y : 0) * g.Win + (g.off_x < 0 ? -g.off_x : 0)) * p.Cin * 4;
+    const int b_bias = ((g.off_y < 0 ? -g.off_y : 0) * g.Win + (g.off_x < 0 ? -g.off_x : 0)) * p.pix * 4;
     const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - b_bias), 0, p.x_bytes + (unsigned)b_bias, 0x00020000);
     if constexpr (VA == 4) {
 #pragma unroll
@@ -1000,7 +1004,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgP p) {
             const int row = bk + i * B_RSTEP;
             b_dy[i] = (row >> g.logW) * g.s_in + dh;
             b_dx[i] = (row & (g.W - 1)) * g.s_in + dw;
-            b_l[i] = (b_jok && row < WBK) ? (unsigned)(((b_dy[i] * g.Win + b_dx[i]) * p.Cin + ci) * 4 + b_bias) : BUF_OOB;
+            b_l[i] = (b_jok && row < WBK) ? (unsigned)(((b_dy[i] * g.Win + b_dx[i]) * p.pix + ci) * 4 + b_bias) : BUF_OOB;
         }
     }
 
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgP p) {
             if constexpr (fastb) {
                 const int n = mb >> (g.logH + g.logW);
                 const int oys = ((mb >> g.logW) & (g.H - 1)) * g.s_in, oxs = (mb & (g.W - 1)) * g.s_in;
-                const unsigned u = (unsigned)((((n * g.Hin + oys) * g.Win) + oxs) * p.Cin * 4);
+                const unsigned u = (unsigned)((((n * g.Hin + oys) * g.Win) + oxs) * p.pix * 4);
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
                     const bool v = (unsigned)(oys + b_dy[i]) < (unsigned)He && (unsigned)(oxs + b_dx[i]) < (unsigned)We;
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgP p) {
                     const int iy = ((m >> g.logW) & (g.H - 1)) * g.s_in + dh;
                     const int ix = (m & (g.W - 1)) * g.s_in + dw;
                     const bool v = b_jok && row < WBK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
-                    const unsigned off = (unsigned)((((n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci) * 4 + b_bias);
+                    const unsigned off = (unsigned)((((n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.pix + ci) * 4 + b_bias);
                     const f32x4 val = buf_load4(rxb, v ? off : BUF_OOB, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rb[i][e] = val[e];
@@ -1066,7 +1070,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgP p) {
                 const int iy = ((m >> g.logW) & (g.H - 1)) * g.s_in + dh;
                 const int ix = (m & (g.W - 1)) * g.s_in + dw;
                 const bool v = b_jok && row < WBK && m < mend && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
-                const long long off = ((long long)(n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.Cin + ci;
+                const long long off = ((long long)(n * g.Hin + (iy >> g.ups)) * g.Win + (ix >> g.ups)) * p.pix + ci;
                 rb[i][0] = v ? p.x[off] : 0.f;
             }
         }
@@ -1666,7 +1670,7 @@ template <int BMODE>
 static bool launch_patch(const ConvP& p, size_t y_elems, hipStream_t st, int want, bool table_hit) {
     const Geo& g = p.g;
     if (g.pc || g.ups || g.s_in != 1 || g.s_in_x != 1 || g.os != 1 || g.Th != 3 || g.Tw != 3) return false;
-    if (p.Ca % 16 != 0 || p.Cb < 32 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return false;
+    if (p.Ca % 16 != 0 || p.pix != p.Ca || p.Cb < 32 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return false;
     if (BMODE == 1 && p.Cb % 4 != 0) return false;
     const int HW = g.H * g.W;
     if (HW < 64) return false;
@@ -1716,8 +1720,55 @@ static void launch_f16_cfg(ConvP p, size_t y_elems, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, TM, TN>), dim3(gx, gy, p.ksplit * ncls), dim3(256), 0, st, p);
 }
 
+// patch-resident fp16 launch of a plain 3x3 convolution (conv_igemm_patch_f16_kernel); split-K in whole 32-channel chunks
+template <int BM, int BN, int TM, int TN>
+static void launch_patch_f16_cfg(ConvP p, size_t y_elems, hipStream_t st) {
+    const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
+    const int chunks = p.Ca / 32, T = 9;
+    int ks = plan_ksplit((long long)gx * gy, chunks * T, BM * BN, p.tune_ks);
+    if (ks > chunks) ks = chunks;
+    const int cps = (chunks + ks - 1) / ks;
+    p.ksplit = (chunks + cps - 1) / cps;
+    p.kper = cps * T;
+    if (t_plan_out) {
+        const int32_t v[8] = {0, BM, BN, p.ksplit, gx, gy, p.ksplit, 2};
+        for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
+        return;
+    }
+    if (p.ksplit > 1 && p.post_slope != 1.f) {
+        gim_set_error("conv fwd: post_slope with a launch that splits K (ask gim_conv_launch_plan first)");
+        t_launch_refused = true;
+        return;
+    }
+    if (p.ksplit > 1 && !p.y_zeroed) (void)hipMemsetAsync(p.y, 0, y_elems * sizeof(float), st);
+    const int Wt = p.g.W < BM ? p.g.W : BM;
+    const int PP = (BM / Wt + 2) * (Wt + 2);
+    const int P_SZ = (PP * 40 + 7) & ~7;
+    const size_t lds = (size_t)(2 * P_SZ + 2 * BN * 40) * sizeof(_Float16);
+    hipLaunchKernelGGL((conv_igemm_patch_f16_kernel<BM, BN, TM, TN>), dim3(gx, gy, p.ksplit), dim3(256), lds, st, p);
+}
+
+static bool launch_patch_f16(const ConvP& p, size_t y_elems, hipStream_t st) {
+    const Geo& g = p.g;
+    if (g.pc || g.ups || g.s_in != 1 || g.s_in_x != 1 || g.os != 1 || g.Th != 3 || g.Tw != 3) return false;
+    const int HW = g.H * g.W;
+    if (HW < 64 || g.W < 2) return false;
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cb + 127) / 128);
+    const bool big = HW >= 128 && g.W <= 64 && t128 >= 256;      // 128-row tiles: whole image rows, enough of them to fill the chip
+    if (p.Cb > 64) {
+        if (big) launch_patch_f16_cfg<128, 128, 2, 2>(p, y_elems, st);
+        else if (p.M > 64 && t128 >= GIM_SMALL_TILES) launch_patch_f16_cfg<64, 128, 1, 2>(p, y_elems, st);
+        else launch_patch_f16_cfg<64, 64, 1, 1>(p, y_elems, st);
+    } else {
+        if (big || (HW >= 128 && g.W <= 64 && t128 >= GIM_SMALL_TILES)) launch_patch_f16_cfg<128, 64, 2, 1>(p, y_elems, st);
+        else launch_patch_f16_cfg<64, 64, 1, 1>(p, y_elems, st);
+    }
+    return true;
+}
+
 static bool launch_f16(const ConvP& p, size_t y_elems, hipStream_t st) {
-    if (p.Ca % 32 != 0 || p.Cb < 32 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return false;
+    if (p.Ca % 32 != 0 || p.pix != p.Ca || p.Cb < 32 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return false;
+    if (launch_patch_f16(p, y_elems, st)) return true;
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cb + 127) / 128) * (p.g.pc ? 4 : 1);
     if (p.Cb > 64) {
         if (p.M <= 64 || t128 < GIM_SMALL_TILES) launch_f16_cfg<64, 64, 1, 1>(p, y_elems, st);
@@ -1796,7 +1847,7 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
     const bool up_fold = s->ups && s->wfold;
     p.g = s->pool ? geo_s2(s, false) : (up_fold ? geo_pc(s, 0) : geo_plain(s, false));
     p.x = x; p.w = w; p.bias = bias; p.sigma = sigma; p.res = residual; p.mask_x = nullptr; p.y = y;
-    p.Ca = s->Cin; p.Cb = s->Cout; p.Cin_w = s->Cin;
+    p.Ca = s->Cin; p.Cb = s->Cout; p.Cin_w = s->Cin; p.pix = s->Cin;
     p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cin;
     {
         const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.Ca * 4ull;
@@ -1847,7 +1898,7 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
     // [N,H/2,W/2,Cin] directly from dy [N,H,W,Cout] by a stride-2 gather; plain: dx at the conv's resolution
     p.g = s->pool ? geo_pc(s, 1) : (up_fold ? geo_s2(s, true) : geo_plain(s, true));
     p.x = dy; p.w = w; p.bias = nullptr; p.sigma = sigma; p.res = nullptr; p.mask_x = mask_x; p.y = dx;
-    p.Ca = s->Cout; p.Cb = s->Cin; p.Cin_w = s->Cin;
+    p.Ca = s->Cout; p.Cb = s->Cin; p.Cin_w = s->Cin; p.pix = s->Cout;
     p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cout;
     {
         const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.Ca * 4ull;
@@ -1922,7 +1973,7 @@ extern "C" int gim_conv2d_dgrad_xfold(const float* dy, const float* wx, const fl
     g.os = 1;
     p.g = g;
     p.x = dy; p.w = wx; p.bias = nullptr; p.sigma = sigma; p.res = nullptr; p.mask_x = mask_x; p.y = dx;
-    p.Ca = s->Cout; p.Cb = J * s->Cin; p.Cin_w = s->Cout;
+    p.Ca = s->Cout; p.Cb = J * s->Cin; p.Cin_w = s->Cout; p.pix = s->Cout;
     p.M = g.N * g.H * g.W; p.Ktot = g.Th * g.Tw * s->Cout;
     p.x_bytes = (unsigned)((unsigned long long)s->N * s->H * s->W * s->Cout * 4ull);
     p.pre_slope = 1.f; p.mask_slope = s->pre_slope; p.out_scale = 1.f; p.res_ups = 0; p.post_slope = 1.f;
@@ -1932,6 +1983,108 @@ extern "C" int gim_conv2d_dgrad_xfold(const float* dy, const float* wx, const fl
     launch_igemm<0, 0>(p, y_elems, (hipStream_t)stream);
     if (t_plan_out) return GIM_OK;
     return gim_check_launch("gim_conv2d_dgrad_xfold");
+}
+
+// -------------------------------------------------------------------------------------------------
+// Row-contiguous K for the image layers (<= 8 input channels; plain stride-1 convolutions; K * Cin <= 64): in NHWC memory the K
+// taps of one tap ROW of an output pixel are K * Cin CONTIGUOUS floats (pixels x - pad .. x + pad, all channels).  On a zero-padded,
+// already activated copy of the image (gim_pad_image) the convolution is therefore an implicit GEMM with K "taps" (the rows) of
+// CaP = K * Cin rounded up to 16 "channels" each, whose pixel stride is Cin floats instead of CaP: the fast path's 16-byte
+// vector loads and wave-uniform K-step offsets, where the generic-K path gathers scalars with a (tap, channel) decode per element
+// (9x9 6->64: 0.35 ms at 58 TFLOP/s; 3x3 3->64: 20-40 TFLOP/s).  The columns beyond K * Cin of a row read the next pixels' data and
+// meet zero weights (gim_conv2d_pack_rows_weights); reads beyond the tensor return 0 (buffer bounds).  The same view gives the
+// weight gradient its B operand (gim_conv2d_wgrad_rows_acc): dW slot [Cout][K][CaP], un-padded by the batched finish (fold = 3).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_rows_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int K, int CaP) {
+    const int total = Cout * K * CaP;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c = i % CaP, r = i / CaP;     // r = co * K + ta
+        wp[i] = c < K * Cin ? w[r * K * Cin + c] : 0.f;
+    }
+}
+
+extern "C" int gim_conv2d_pack_rows_weights(const float* w, float* wp, int Cout, int Cin, int KH, void* stream) {
+    GIM_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && (KH & 1) && KH * Cin <= 64, "pack_rows_weights: bad args");
+    const int CaP = (KH * Cin + 15) & ~15, total = Cout * KH * CaP;
+    hipLaunchKernelGGL(pack_rows_weights_kernel, dim3((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024), dim3(256), 0, (hipStream_t)stream,
+                       w, wp, Cout, Cin, KH, CaP);
+    return gim_check_launch("gim_conv2d_pack_rows_weights");
+}
+
+// xp[n][y + pad][x + pad][c] = lrelu(x[n][y][x][c], slope), zero border of `pad` pixels: [N, H + 2 pad, W + 2 pad, C]
+__global__ __launch_bounds__(256) void pad_image_kernel(const float* __restrict__ x, float* __restrict__ xp, int N, int H, int W, int C, int pad, float slope) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const long long total = (long long)N * Hp * Wp * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int xx = (int)(r % Wp) - pad; r /= Wp;
+        const int yy = (int)(r % Hp) - pad;
+        const int n = (int)(r / Hp);
+        float v = 0.f;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long long)n * H + yy) * W + xx) * C + c];
+        xp[i] = fmaxf(v, v * slope);
+    }
+}
+
+extern "C" int gim_pad_image(const float* x, float* xp, int N, int H, int W, int C, int pad, float slope, void* stream) {
+    GIM_CHECK_ARG(x && xp && N > 0 && H > 0 && W > 0 && C > 0 && pad >= 0 && slope > 0.f && slope <= 1.f, "pad_image: bad args");
+    const long long total = (long long)N * (H + 2 * pad) * (W + 2 * pad) * C;
+    hipLaunchKernelGGL(pad_image_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       x, xp, N, H, W, C, pad, slope);
+    return gim_check_launch("gim_pad_image");
+}
+
+static int rows_shape_ok(const gim_conv_shape* s) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    GIM_CHECK_ARG(!s->ups && !s->pool && !s->wfold && !s->res_ups, "conv rows form: plain stride-1 convolutions only");
+    GIM_CHECK_ARG(s->Cin <= 8 && s->KH * s->Cin <= 64 && s->Cout >= 16, "conv rows form: <= 8 input channels, K * Cin <= 64, >= 16 output channels");
+    return GIM_OK;
+}
+
+static Geo geo_rows(const gim_conv_shape* s) {
+    Geo g{};
+    const int pad = (s->KH - 1) / 2;
+    geo_grid(g, s->N, s->H, s->W);
+    g.ups = 0; g.Hin = s->H + 2 * pad; g.Win = s->W + 2 * pad;
+    g.s_in = g.s_in_x = 1; g.off_y = g.off_x = 0;
+    g.Th = g.KF = s->KH; g.Tw = g.KFw = 1;
+    g.wa_base = 0; g.wa_step = 1; g.wb_base = 0; g.wb_step = 0;
+    g.os = 1;
+    return g;
+}
+
+// y = conv(xp, w) / sigma + bias + residual on the padded, activated copy xp = gim_pad_image(x) and wp = gim_conv2d_pack_rows_weights(w)
+extern "C" int gim_conv2d_fwd_rows(const float* xp, const float* wp, const float* bias, const float* sigma, const float* residual,
+                                   float* y, const gim_conv_shape* s, void* stream) {
+    int rc = rows_shape_ok(s);
+    if (rc) return rc;
+    GIM_CHECK_ARG(xp && wp && y && !((uintptr_t)xp & 15) && !((uintptr_t)wp & 15), "conv fwd (rows form): null or unaligned pointer");
+    ConvP p{};
+    p.zero = zero_page();
+    p.pos_inf = __builtin_inff();
+    p.g = geo_rows(s);
+    const int CaP = (s->KH * s->Cin + 15) & ~15;
+    p.x = xp; p.w = wp; p.bias = bias; p.sigma = sigma; p.res = residual; p.mask_x = nullptr; p.y = y;
+    p.Ca = CaP; p.Cb = s->Cout; p.Cin_w = CaP; p.pix = s->Cin;
+    p.M = p.g.N * p.g.H * p.g.W; p.Ktot = s->KH * CaP;
+    const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * s->Cin * 4ull;
+    GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv fwd (rows form): the padded image batch exceeds 2 GiB (32-bit buffer offsets): split the batch");
+    p.x_bytes = (unsigned)xb;
+    p.pre_slope = 1.f; p.mask_slope = 1.f; p.out_scale = 1.f; p.res_ups = 0;
+    GIM_CHECK_ARG(s->post_slope >= 0.f && s->post_slope <= 1.f, "conv fwd: post_slope must be in [0, 1] (0 or 1 = none)");
+    p.post_slope = (s->post_slope > 0.f) ? s->post_slope : 1.f;
+    p.tune_kind = 6;   // no table rows: heuristics (or the caller's tune_* fields)
+    p.tune_tile = s->tune_tile; p.tune_ks = s->tune_ksplit; p.y_zeroed = s->out_zeroed;
+    p.f16 = 0;
+    const size_t y_elems = (size_t)s->N * s->H * s->W * s->Cout;
+    GIM_CHECK_ARG(y_elems * sizeof(float) <= 0x7FFFFFF0ull, "conv: the output exceeds 2 GiB (32-bit buffer offsets): split the batch");
+    t_launch_refused = false;
+    launch_igemm<0, 0>(p, y_elems, (hipStream_t)stream);
+    if (t_launch_refused) return GIM_E_BADARG;
+    if (t_plan_out) return GIM_OK;
+    return gim_check_launch("gim_conv2d_fwd_rows");
 }
 
 // wgrad roles.  plain: A = dy [N,H,W,Cout], B = gathered x.  pool: A = dy [N,H/2,W/2,Cout], B = x gathered with
@@ -2109,11 +2262,23 @@ __global__ __launch_bounds__(64 * NARROW_PARTS) void wgrad_1x1_narrow_kernel(con
 // prezeroed: the caller guarantees slabs / bias_slabs hold zeros (or a partial sum to add to): pixel slices are combined
 // with float atomics and nothing is cleared here (gim_conv2d_wgrad_acc).
 static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias_slabs, int n_slabs, const gim_conv_shape* s,
-                      void* stream, bool prezeroed) {
+                      void* stream, bool prezeroed, bool rows = false) {
     int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(dy && x && slabs, "conv wgrad: null pointer");
-    const WgPlan q = wgrad_plan(s);
+    WgPlan q = wgrad_plan(s);
+    const int CaP = (s->KH * s->Cin + 15) & ~15;
+    if (rows) {   // row-contiguous form: K tap rows of CaP columns each; table rows do not apply (other column count)
+        gim_conv_shape v = *s;
+        v.tune_tile = s->tune_tile ? s->tune_tile : -1;
+        v.prec = 0;
+        q = wgrad_plan(&v);
+        WgPlan q2 = q;
+        q2.cols = s->KH * CaP;
+        q2.bn = q2.cols > 64 ? 128 : 64;
+        if (q2.bm == 32) q2.bn = 128;
+        q = q2;
+    }
     const bool atomic = prezeroed ? true : (n_slabs == 1 && q.ns > 1);
     if (!prezeroed) GIM_CHECK_ARG(n_slabs == 1 || n_slabs == q.ns, "conv wgrad: n_slabs must be 1 (atomic combine) or gim_conv2d_wgrad_slabs(shape)");
     const bool up_fold = s->ups && s->wfold;
@@ -2121,18 +2286,20 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     WgP p{};
     p.zero = zero_page();
     p.pos_inf = __builtin_inff();
-    if (s->pool) p.g = geo_s2(s, false);
+    if (rows) p.g = geo_rows(s);
+    else if (s->pool) p.g = geo_s2(s, false);
     else if (up_fold) p.g = geo_s2(s, false);
     else p.g = geo_plain(s, false);
     if (up_fold) {
-        p.dy = x; p.x = dy; p.Cin = s->Cout; p.Cout = s->Cin; p.pre_slope = 1.f; p.a_slope = s->pre_slope;
+        p.dy = x; p.x = dy; p.Cin = s->Cout; p.Cout = s->Cin; p.pre_slope = 1.f; p.a_slope = s->pre_slope; p.pix = s->Cout;
     } else {
-        p.dy = dy; p.x = x; p.Cin = s->Cin; p.Cout = s->Cout; p.pre_slope = s->pre_slope; p.a_slope = 1.f;
+        p.dy = dy; p.x = x; p.Cin = s->Cin; p.Cout = s->Cout; p.pre_slope = s->pre_slope; p.a_slope = 1.f; p.pix = s->Cin;
     }
     p.slabs = slabs; p.bias_slabs = bias_slabs;
     p.M = q.M; p.Kcols = q.cols; p.mper = q.mper; p.atomic = atomic ? 1 : 0;
+    if (rows) { p.Cin = CaP; p.pix = s->Cin; p.pre_slope = 1.f; }   // columns per tap row; the padded copy is already activated
     {
-        const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.Cin * 4ull;
+        const unsigned long long xb = (unsigned long long)p.g.N * p.g.Hin * p.g.Win * p.pix * 4ull;
         GIM_CHECK_ARG(xb <= 0x7FFFFFF0ull, "conv wgrad: gathered tensor larger than 2 GiB (32-bit buffer offsets): split the batch");
         p.x_bytes = (unsigned)xb;
     }
@@ -2141,7 +2308,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
         if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
     }
     // 3 -> 3 / 1 -> 1 image layers, slices combined by atomics: the direct kernel (conv_tiny.hip)
-    if ((prezeroed || n_slabs == 1) && s->tune_tile == 0 && s->tune_wgrad == 0 && gim_tiny_shape(s)) {
+    if (!rows && (prezeroed || n_slabs == 1) && s->tune_tile == 0 && s->tune_wgrad == 0 && gim_tiny_shape(s)) {
         if (!prezeroed && !atomic && !t_plan_out) {   // (atomic: the memsets above have run)
             (void)hipMemsetAsync(slabs, 0, (size_t)q.rows * q.cols * sizeof(float), (hipStream_t)stream);
             if (bias_slabs) (void)hipMemsetAsync(bias_slabs, 0, (size_t)q.rows * sizeof(float), (hipStream_t)stream);
@@ -2151,7 +2318,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
     }
     // plain 3x3, row-resident kernel: on request (tile code >= 20000 from the caller or the table row; ks / target = workgroups wanted)
     // (W >= 4: the narrowest instantiation walks rows of 4 pixels - a non-square 8 x 2 map passes H * W >= 16 and must not run it)
-    if (q.patch && atomic && s->KH == 3 && !s->wfold && !s->ups && !s->pool && s->Cin % 32 == 0 && s->Cout % 128 == 0 && s->H * s->W >= 16 &&
+    if (!rows && q.patch && atomic && s->KH == 3 && !s->wfold && !s->ups && !s->pool && s->Cin % 32 == 0 && s->Cout % 128 == 0 && s->H * s->W >= 16 &&
         s->W >= 4 && !((uintptr_t)dy & 15) && !((uintptr_t)x & 15)) {
         const int tiles = 3 * (s->Cin / 32) * (s->Cout / 128);
         long long S = ((q.patch_target > 0 ? q.patch_target : 1024) + tiles - 1) / tiles;
@@ -2175,7 +2342,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* bias
         return gim_check_launch("gim_conv2d_wgrad");
     }
     // 1x1 convolution with <= 8 channels on one side, atomic combine: the outer-product kernel (no table row: nothing to choose)
-    if (s->KH == 1 && !s->wfold && !s->ups && !s->pool && atomic && (s->Cin <= 8 || s->Cout <= 8) && (s->Cin >= 16 || s->Cout >= 16) && q.M % NARROW_U == 0 &&
+    if (!rows && s->KH == 1 && !s->wfold && !s->ups && !s->pool && atomic && (s->Cin <= 8 || s->Cout <= 8) && (s->Cin >= 16 || s->Cout >= 16) && q.M % NARROW_U == 0 &&
         s->tune_tile == 0 && s->tune_wgrad == 0) {   // an explicit tile / slice choice of the caller means the MFMA kernel
         const bool wide_is_dy = s->Cin <= 8;
         const int Cw = wide_is_dy ? s->Cout : s->Cin, Cn = wide_is_dy ? s->Cin : s->Cout;
@@ -2237,6 +2404,16 @@ extern "C" int gim_conv2d_wgrad_acc(const float* dy, const float* x, float* acc,
         }
     }
     return wgrad_impl(dy, x, acc, bias_acc, 1, s, stream, true);
+}
+
+// dW slot [Cout][K][CaP] (+)= dy^T * rows(xp), bias slot += column sums of dy: the weight gradient of the row-contiguous form
+// (xp = gim_pad_image(x): padded AND activated); slices combine by float atomics into the caller's pre-zeroed slot, the batched
+// finish un-pads it (gim_wgrad_job.fold = 3).
+extern "C" int gim_conv2d_wgrad_rows_acc(const float* dy, const float* xp, float* acc, float* bias_acc, const gim_conv_shape* s, void* stream) {
+    int rc = rows_shape_ok(s);
+    if (rc) return rc;
+    GIM_CHECK_ARG(s->Cout % 4 == 0 && dy && xp && !((uintptr_t)dy & 15) && !((uintptr_t)xp & 15), "conv wgrad (rows form): Cout % 4 == 0 and 16-byte aligned operands required");
+    return wgrad_impl(dy, xp, acc, bias_acc, 1, s, stream, true, true);
 }
 
 // The launch a conv entry point would make for `shape`, without launching anything (tests, tools/conv_autotune.py).

@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void conv_tiny_wgrad_kernel(const TinyP p) {  
         dys[idx] = (oy < p.H && ox < p.W) ? dyi[((long long)oy * p.W + ox) * CO + c] : 0.f;
     }
     __syncthreads();
+    // the G pixel groups of one (tap, channel) are summed through LDS first: ONE atomic per weight-gradient element and workgroup
+    // (with G = 9 groups a 3x3 layer sent 9 x 1280 adds to each of its 81 addresses: same-address atomics serialize - 0.70 ms)
+    __shared__ float red[256 * CO];
     if (t < G * NT) {
         const int grp = t / NT, id = t - grp * NT;
         const int ci = id % CI, tap = id / CI, tb = tap % K, ta = tap / K;
@@ -118,7 +121,15 @@ __global__ __launch_bounds__(256) void conv_tiny_wgrad_kernel(const TinyP p) {  
             for (int c = 0; c < CO; ++c) acc[c] += dys[pp * CO + c] * xv;
         }
 #pragma unroll
-        for (int c = 0; c < CO; ++c) atomicAdd(&p.out[((c * K + ta) * K + tb) * CI + ci], acc[c]);
+        for (int c = 0; c < CO; ++c) red[(grp * NT + id) * CO + c] = acc[c];
+    }
+    __syncthreads();
+    for (int o = t; o < NT * CO; o += 256) {     // o = id * CO + c
+        const int id = o / CO, c = o - id * CO;
+        float v = 0.f;
+        for (int gq = 0; gq < G; ++gq) v += red[(gq * NT + id) * CO + c];
+        const int ci = id % CI, tap = id / CI, tb = tap % K, ta = tap / K;
+        atomicAdd(&p.out[((c * K + ta) * K + tb) * CI + ci], v);
     }
     if (p.out2 && t >= 256 - CO) {     // the last CO threads (idle above whenever G * NT < 256 - always true for these shapes' bias lanes or cheap otherwise)
         const int c = t - (256 - CO);

@@ -398,6 +398,8 @@ __device__ __forceinline__ float wgq_load(const gim_wgrad_job& jb, unsigned i) {
     const unsigned K = jb.K, KF = K + 1, Cin = jb.Cin, Cout = jb.Cout;
     const unsigned r1 = i / Cin, ci = i - r1 * Cin;
     const unsigned r2 = r1 / K, kw = r1 - r2 * K;
+    if (jb.fold == 3)   // row-padded slot of gim_conv2d_wgrad_rows_acc: [Cout][K][K * Cin rounded up to 16]
+        return jb.src[r2 * ((K * Cin + 15u) & ~15u) + kw * Cin + ci];
     const unsigned co = r2 / K, kh = r2 - co * K;
     float g = 0.f;
 #pragma unroll

@@ -507,14 +507,26 @@ class ConvFn(Function):
             if x.dim() != 4 or _splits_k(sh, 0, key):
                 raise RuntimeError("conv: an activated output (post_slope) cannot be combined with a split-K launch or a linear layer")
             sh.post_slope = post_slope
-        y = _conv_out(sh, 0, key, (N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), x.device)
         if res is not None:
             res = _req(res, "res")
-        if fold and wf is None:
-            wf = _folded(wp, Cout, Cin, KH)
-        wk = wf if fold else wp
-        check(lib.gim_conv2d_fwd(_p(x), _p(wk), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd")
-        ctx.save_for_backward(x, w, sigma, u_s, v_s, wf if fold else None, bias)
+        xp = None
+        if _ROWS_FORM and x.dim() == 4 and KH >= 3 and Cin <= 8 and KH * Cin <= 64 and Cout >= 16 and Cout % 4 == 0 and not (ups or pool or res_ups) \
+                and sh.tune_tile == 0:
+            # image layers: row-contiguous K on a zero-padded, activated copy of the image (include/gim_hip.h gim_conv2d_fwd_rows)
+            pad = (KH - 1) // 2
+            xp = torch.empty((N, H + 2 * pad, W + 2 * pad, Cin), device=x.device, dtype=torch.float32)
+            check(lib.gim_pad_image(_p(x), _p(xp), N, H, W, Cin, pad, 1.0 if x_act else pre_slope, _stream()), "pad_image")
+            wrows = _transposed(lib, w, wp, Cout, Cin, KH, rows=True)
+            sh.tune_ksplit = 1      # one K slice: these layers have >= 10^5 output pixels; keeps an activated output (post_slope) legal
+            y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+            check(lib.gim_conv2d_fwd_rows(_p(xp), _p(wrows), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd_rows")
+        else:
+            y = _conv_out(sh, 0, key, (N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), x.device)
+            if fold and wf is None:
+                wf = _folded(wp, Cout, Cin, KH)
+            wk = wf if fold else wp
+            check(lib.gim_conv2d_fwd(_p(x), _p(wk), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd")
+        ctx.save_for_backward(x, w, sigma, u_s, v_s, wf if fold else None, bias, xp)
         ctx.cfg = (N, H, W, Cin, Cout, KH, ups, pre_slope, bias is not None, res is not None, bool(pool), fold, bool(res_ups))
         ctx.guard = guard
         ctx.x_act = bool(x_act)
@@ -525,7 +537,7 @@ class ConvFn(Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, w, sigma, u_s, v_s, wf, bias = ctx.saved_tensors
+        x, w, sigma, u_s, v_s, wf, bias, xp = ctx.saved_tensors
         N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = ctx.cfg
         dy = _req(dy, "dy")
         if ctx.guard is not None and ctx.guard[0].stale(ctx.guard[1]):
@@ -555,7 +567,7 @@ class ConvFn(Function):
             if ctx.x_act or _TUNE_OVERRIDE:   # x_act: the stored x is already lrelu(x): no activation on the wgrad operand
                 sh_w = _tuned(_shape(N, H, W, Cin, Cout, KH, ups, 1.0 if ctx.x_act else pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0),
                               "wgrad", (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold))
-            dw, db = _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh_w, ctx.cfg, want_b, st)
+            dw, db = _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh_w, ctx.cfg, want_b, st, xp)
         elif want_b:
             db = torch.empty(Cout, device=dev, dtype=torch.float32)
             scratch = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
@@ -570,23 +582,28 @@ class ConvFn(Function):
 
 
 _ACT_STORAGE = os.environ.get("GIM_NO_ACT_STORAGE") is None   # A/B switch (host side)
+_ROWS_FORM = os.environ.get("GIM_NO_ROWS_FORM") is None   # A/B switch (host side): row-contiguous K for the image layers
 _NARROW_DGRAD_T = os.environ.get("GIM_NO_NARROW_DGRAD_T") is None   # A/B switch (host side)
 _NARROW_XFOLD = os.environ.get("GIM_NO_NARROW_XFOLD") is None   # A/B switch (host side)
 _WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
 
 
-def _transposed(lib, w, wk, Cout, Cin, KF, xfold=0):
+def _transposed(lib, w, wk, Cout, Cin, KF, xfold=0, rows=False):
     """WT[Cin][KF][KF][Cout] of the (plain or folded) weights `wk` of parameter `w` - or, xfold = J, the x-folded
-    WX[J * Cin][KF][KF + J - 1][Cout] of gim_conv2d_xfold_weights - recomputed only when the weights changed (autograd version
+    WX[J * Cin][KF][KF + J - 1][Cout] of gim_conv2d_xfold_weights; or, rows, the row-padded WP[Cout][KF][KF * Cin -> 16] of
+    gim_conv2d_pack_rows_weights - recomputed only when the weights changed (autograd version
     counter for torch-side writes, optim.weights_epoch for the fused Adam kernel)."""
     from . import optim
     key = (w._version, optim.weights_epoch(w))
-    slot = (w.data_ptr(), KF, xfold)
+    slot = (w.data_ptr(), KF, "rows" if rows else xfold)
     ent = _WT_CACHE.get(slot)
     raw = _stream()
     if ent is None or ent[0] != key or ent[4]() is not w:
         cur = torch.cuda.current_stream()
-        if xfold:
+        if rows:
+            wt = torch.empty(Cout * KF * ((KF * Cin + 15) & ~15), device=wk.device, dtype=torch.float32)
+            check(lib.gim_conv2d_pack_rows_weights(_p(wk), _p(wt), Cout, Cin, KF, raw), "pack_rows_weights")
+        elif xfold:
             wt = torch.empty(xfold * Cin * KF * (KF + xfold - 1) * Cout, device=wk.device, dtype=torch.float32)
             check(lib.gim_conv2d_xfold_weights(_p(wk), _p(wt), Cout, Cin, KF, xfold, raw), "xfold_weights")
         else:
@@ -649,8 +666,10 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
     return dx
 
 
-def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
-    """(dw, db) of one convolution; either may come back None because it was ADDED into the parameter's .grad."""
+def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st, xp=None):
+    """(dw, db) of one convolution; either may come back None because it was ADDED into the parameter's .grad.
+    xp: the padded, activated copy of x that a forward in the row-contiguous form made (image layers): the queued path then takes
+    the weight gradient from it (gim_conv2d_wgrad_rows_acc)."""
     N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
     if _FLOPS is not None:
         _note_conv("wgrad", cfg)
@@ -678,14 +697,18 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st):
         if Cout * KFF >= 1 << 31:
             raise RuntimeError("weight gradient of more than 2^31 elements (gim_wgrad_finish_batched indexes with 32 bits)")
         n_chunks = (n + q.CHUNK - 1) // q.CHUNK
-        src = q.take(Cout * KFF, dev)
+        rows = xp is not None and dy.is_contiguous()
+        src = q.take(Cout * KH * ((KH * Cin + 15) & ~15) if rows else Cout * KFF, dev)
         bsrc = q.take(Cout, dev) if slab_bias else None
         sn = sigma is not None
-        tmp = q.take(n, dev) if (fold and sn) else None
+        tmp = q.take(n, dev) if ((fold or rows) and sn) else None
         part = q.take(n_chunks, dev) if sn else None
-        check(lib.gim_conv2d_wgrad_acc(_p(dy), _p(x), src, bsrc, sh, st), "conv2d_wgrad_acc")
+        if rows:   # slot [Cout][KH][KH * Cin -> 16]; the batched finish un-pads it (fold code 3)
+            check(lib.gim_conv2d_wgrad_rows_acc(_p(dy), _p(xp), src, bsrc, sh, st), "conv2d_wgrad_rows_acc")
+        else:
+            check(lib.gim_conv2d_wgrad_acc(_p(dy), _p(x), src, bsrc, sh, st), "conv2d_wgrad_acc")
         q.add((src, bsrc or 0, _p(wp) if sn else 0, _p(sigma) or 0, _p(u_s) or 0, _p(v_s) or 0, tmp or 0, part or 0,
-               _p(acc_w), _p(acc_b) or 0, Cout, Cin, KH, (2 if ups else 1) if fold else 0, n_chunks), (sigma, u_s, v_s))
+               _p(acc_w), _p(acc_b) or 0, Cout, Cin, KH, 3 if rows else ((2 if ups else 1) if fold else 0), n_chunks), (sigma, u_s, v_s))
         if want_b and not slab_bias:
             scr = torch.empty(256 * Cout, device=dev, dtype=torch.float32)
             tgt_b = _grad_target(bias)

@@ -250,6 +250,42 @@ def test_conv2d_residual_upsampled():
     assert relerr(nchw(rg.grad), res.grad) < TOL
 
 
+@pytest.mark.parametrize("N,Cin,Cout,K,H,slope,x_act", [(3, 6, 64, 9, 32, 0.2, False), (4, 3, 64, 3, 16, 0.2, True), (2, 1, 32, 3, 16, 0.2, False),
+                                                       (2, 6, 48, 9, 8, 1.0, False)])
+def test_image_layer_rows_form_through_the_gradient_bucket(N, Cin, Cout, K, H, slope, x_act):
+    """The row-contiguous form of the image layers (gim_pad_image + gim_conv2d_pack_rows_weights + gim_conv2d_fwd_rows, and
+    gim_conv2d_wgrad_rows_acc with the batched finish's un-padding, fold code 3) as the TRAINING STEP runs it: weight and bias own
+    pre-existing .grad buffers (the optimizer's flat bucket), so the weight gradient goes through the queue and is ADDED there, with
+    the spectral-norm chain rule - against fp64 autograd of F.conv2d(lrelu(x), w / sigma(w)) + bias."""
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
+    assert ops._ROWS_FORM
+    tag = "rows%s" % ((N, Cin, Cout, K, H, slope, x_act),)
+    x = T(pf.normal(tag + "x", (N, Cin, H, H))).requires_grad_()
+    w = T(pf.normal(tag + "w", (Cout, Cin, K, K)) / np.sqrt(Cin * K * K)).requires_grad_()
+    b = T(pf.normal(tag + "b", (Cout,))).requires_grad_()
+    u = T(pf.normal(tag + "u", (Cout,)))
+    v = T(pf.normal(tag + "v", (Cin * K * K,)))
+    u, v = u / u.norm(), v / v.norm()
+    sigma = torch.dot(u, torch.mv(w.reshape(Cout, -1), v))          # differentiated w.r.t. w with u, v constant (spectral norm)
+    y = F.conv2d(F.leaky_relu(x, slope) if slope != 1.0 else x, w / sigma, b, padding=(K - 1) // 2)
+    r = T(pf.uniform(tag + "dy", tuple(y.shape)))
+    (y * r).sum().backward()
+    xin = nhwc(F.leaky_relu(x, slope) if x_act else x).requires_grad_()
+    wg = cl_weight(w)
+    bg = b.detach().float().to(dev()).requires_grad_()
+    pre = 0.25
+    wg.grad = torch.full_like(wg, pre)       # channels-last like the parameter: the bucket's memory order
+    bg.grad = torch.full_like(bg, pre)
+    sg = sigma.detach().float().reshape(1).to(dev())
+    yg = ops.conv2d(xin, wg, bg, None, sg, u.float().to(dev()), v.float().to(dev()), 0, slope, x_act=x_act)
+    assert relerr(nchw(yg), y) < TOL, "forward"
+    (yg * nhwc(r)).sum().backward()
+    assert not ops.wgrad_queue.jobs, "the queue was flushed at the end of backward"
+    assert relerr(nchw(xin.grad), x.grad) < TOL, "dx"
+    assert relerr((wg.grad - pre).double().cpu(), w.grad) < TOL, "dw (added into the existing buffer, through sigma)"
+    assert relerr((bg.grad - pre).double().cpu(), b.grad) < TOL, "db"
+
+
 def test_linear_fwd_bwd():
     from optimalstrategiesagainstgenerativeattacks_amd import ops
     for rows, din, dout, slope in [(5, 6, 10, 1.0), (80, 512, 1024, 0.2), (16, 320, 1, 0.2), (240, 96, 64, 1.0)]:

@@ -77,7 +77,21 @@ def main():
         slabs = torch.zeros(ns * Cout * KF * KF * Cin, device=dev)
         flops = ops.conv_executed_flops(N, H, W, Cin, Cout, KH, ups, pool, fold)      # what the kernels execute (folds!)
         algo = ops.conv_algorithmic_flops(N, H, W, Cin, Cout, KH)                      # the unfused reference op
-        t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
+        rows_form = ops._ROWS_FORM and KH >= 3 and Cin <= 8 and KH * Cin <= 64 and Cout >= 16 and Cout % 4 == 0 and not (ups or pool)
+        if rows_form:   # as ops.ConvFn: padded + activated image copy, row-contiguous K (the copy is part of the forward's time)
+            pad = (KH - 1) // 2
+            CaP = (KH * Cin + 15) & ~15
+            xp = torch.empty(N, H + 2 * pad, W + 2 * pad, Cin, device=dev)
+            wr = torch.empty(Cout * KH * CaP, device=dev)
+            lib.gim_conv2d_pack_rows_weights(w.data_ptr(), wr.data_ptr(), Cout, Cin, KH, st)
+            shr = _lib.GimConvShape(N, H, W, Cin, Cout, KH, 0, 1.0, 0, 0, 0, 0, 1)
+
+            def fwd_rows():
+                lib.gim_pad_image(x.data_ptr(), xp.data_ptr(), N, H, W, Cin, pad, slope, st)
+                lib.gim_conv2d_fwd_rows(xp.data_ptr(), wr.data_ptr(), None, None, None, y.data_ptr(), shr, st)
+            t_f = time_ms(fwd_rows)
+        else:
+            t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
         J = ops._xfold_factor(Cin, W) if (KH >= 3 and not (ups or pool or fold) and Cout % 16 == 0 and ops._NARROW_XFOLD) else 0
         if J:   # as ops._conv_dgrad: x-folded gradient w.r.t. images
             wx = torch.empty(J * Cin * KH * (KH + J - 1) * Cout, device=dev)
@@ -90,8 +104,13 @@ def main():
         else:
             t_d = time_ms(lambda: lib.gim_conv2d_dgrad(y.data_ptr(), w.data_ptr(), None, None, dx.data_ptr(), sh, st)) if n_dx else 0.0
 
+        slabs_r = torch.zeros(Cout * KH * ((KH * Cin + 15) & ~15), device=dev) if rows_form else None
+
         def wg():   # the step's form: accumulate into an arena slot (the finish of all convs is two batched launches per pass)
-            lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, sh, st)
+            if rows_form:
+                lib.gim_conv2d_wgrad_rows_acc(y.data_ptr(), xp.data_ptr(), slabs_r.data_ptr(), None, shr, st)
+            else:
+                lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, sh, st)
         t_w = time_ms(wg) if n_dw else 0.0
         total = cnt * t_f + n_dx * t_d + n_dw * t_w
         tot["fwd"] += cnt * t_f
