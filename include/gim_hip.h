@@ -104,6 +104,14 @@ int gim_conv2d_fwd(const float* x, const float* w, const float* bias, const floa
 int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
                      const gim_conv_shape* s, void* stream);
 
+/* gim_conv2d_dgrad of a PLAIN convolution with the gradient of a pooled branch of its input folded into the epilogue:
+ * dx = leaky_relu'(mask_x) * conv_transpose(dy, w) / sigma + res_scale * nearest_up2(res_half), res_half [N, H/2, W/2, Cin].
+ * ResBlockDown reads its input twice (models/model_blocks.py:497-514: conv_r1 on lrelu(x), conv_l1 on the raw x, both pooled later);
+ * with res_scale = 0.25 res_half is the gradient w.r.t. avgpool2(x) and the sum is the block's whole input gradient (autograd's
+ * add of the two branches).  mask_x and res_half required. */
+int gim_conv2d_dgrad_res(const float* dy, const float* w, const float* sigma, const float* mask_x, const float* res_half,
+                         float res_scale, float* dx, const gim_conv_shape* s, void* stream);
+
 /* Split-K weight gradient: slabs[i] for i < n_slabs hold partial sums over disjoint pixel ranges of
  * dy^T * im2col(x~): layout [Cout][KH][KW][Cin] (plain), [Cout][KH+1][KH+1][Cin] (pool: gradient of F) or
  * [Cin][KH+1][KH+1][Cout] (ups + wfold: transposed gradient of F; no bias_slabs in this form);  bias_slabs[i] ([Cout] each, may be NULL) the matching partial

@@ -27,6 +27,7 @@ SP = POINTER(GimConvShape)
 SIGNATURES = {
     "gim_conv2d_fwd": [P, P, P, P, P, P, SP, P],
     "gim_conv2d_dgrad": [P, P, P, P, P, SP, P],
+    "gim_conv2d_dgrad_res": [P, P, P, P, P, c_float, P, SP, P],
     "gim_conv2d_wgrad_slabs": [SP],
     "gim_conv2d_wgrad": [P, P, P, P, c_int, SP, P],
     "gim_wgrad_finish": [P, P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P],

@@ -91,6 +91,7 @@ struct ConvP {
     int tune_kind;      // host only: row kind of the launch-tuning table (0 fwd, 1 dgrad k-major, 4 dgrad on transposed weights)
     float pos_inf;      // +infinity as a run-time value
     float pre_slope, mask_slope, out_scale;
+    float res_scale;    // dgrad with a half-resolution residual (epilogue MODE 4): its factor
     float post_slope;   // forward: leaky-relu on the stored output (1 = none; never with split-K: the slices are combined by addition)
     int res_ups;  // residual stored at half the output resolution (nearest-upsampled on the fly)
     int ksplit;   // > 1: K-slices over grid.z, partial results combined with float atomics into a pre-zeroed y
@@ -146,6 +147,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 struct EpiCtx {
     __amdgpu_buffer_rsrc_t ry, rr, rm;
     float scale, mask_slope, post_slope;
+    float res_scale;   // MODE 4: factor of the half-resolution residual (0.25: the average pool's backward)
     int M, Cb, logH, logW, Hm1, Wm1, os, py, px, Ho, Wo;
     bool atom, remap;
 };
@@ -157,7 +159,7 @@ __device__ __forceinline__ void epi_elem_off(const EpiCtx& c, int m, int co, uns
     const int oy = ((m >> c.logW) & c.Hm1) * c.os + c.py;
     const int ox = (m & c.Wm1) * c.os + c.px;
     o = (unsigned)((((n * c.Ho + oy) * c.Wo + ox) * c.Cb + co) * 4);
-    if constexpr (MODE == 2) ro = (unsigned)((((n * (c.Ho >> 1) + (oy >> 1)) * (c.Wo >> 1) + (ox >> 1)) * c.Cb + co) * 4);
+    if constexpr (MODE == 2 || MODE == 4) ro = (unsigned)((((n * (c.Ho >> 1) + (oy >> 1)) * (c.Wo >> 1) + (ox >> 1)) * c.Cb + co) * 4);
 }
 
 template <int NE, int MODE>
@@ -166,10 +168,10 @@ __device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE],
     const unsigned rowb = (unsigned)c.Cb * 4u;
 #pragma unroll
     for (int e0 = 0; e0 < NE; e0 += CH) {
-        unsigned off[CH], roff[MODE == 2 ? CH : 1];
+        unsigned off[CH], roff[(MODE == 2 || MODE == 4) ? CH : 1];
         // rows come in groups of 4 consecutive m (mbase % 4 == 0): one full address computation per group where a group stays in
         // one image row (W >= 4), plain arithmetic otherwise; out-of-range lanes get the high bit (>= num_records: dropped)
-        if (!c.remap && MODE != 2) {
+        if (!c.remap && MODE != 2 && MODE != 4) {
             const unsigned base = (unsigned)((mbase * c.Cb + co) * 4);
 #pragma unroll
             for (int q = 0; q < CH; ++q) off[q] = base + (unsigned)(((e0 + q) & 3) + 8 * ((e0 + q) >> 2)) * rowb;
@@ -181,7 +183,7 @@ __device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE],
 #pragma unroll
                 for (int k = 0; k < 4 && g4 + k < CH; ++k) {
                     off[g4 + k] = o + (unsigned)(k * c.os) * rowb;
-                    if constexpr (MODE == 2) roff[g4 + k] = ro + (unsigned)(((c.px + k * c.os) >> 1) - (c.px >> 1)) * rowb;
+                    if constexpr (MODE == 2 || MODE == 4) roff[g4 + k] = ro + (unsigned)(((c.px + k * c.os) >> 1) - (c.px >> 1)) * rowb;
                 }
             }
         } else {
@@ -189,17 +191,22 @@ __device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE],
             for (int q = 0; q < CH; ++q) {
                 unsigned ro = 0;
                 epi_elem_off<MODE>(c, mbase + ((e0 + q) & 3) + 8 * ((e0 + q) >> 2), co, off[q], ro);
-                if constexpr (MODE == 2) roff[q] = ro;
+                if constexpr (MODE == 2 || MODE == 4) roff[q] = ro;
             }
         }
 #pragma unroll
         for (int q = 0; q < CH; ++q) {
             const unsigned bad = (cok && mbase + ((e0 + q) & 3) + 8 * ((e0 + q) >> 2) < c.M) ? 0u : BUF_OOB;
             off[q] |= bad;
-            if constexpr (MODE == 2) roff[q] |= bad;
+            if constexpr (MODE == 2 || MODE == 4) roff[q] |= bad;
         }
-        float ld[MODE == 0 ? 1 : CH];
-        if constexpr (MODE == 1 || MODE == 2) {
+        float ld[MODE == 0 ? 1 : CH], ld2[MODE == 4 ? CH : 1];
+        if constexpr (MODE == 4) {   // the input-gradient fan-in of a ResBlockDown: mask (full resolution) and the pooled skip gradient (half)
+#pragma unroll
+            for (int q = 0; q < CH; ++q) ld[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rm, off[q], 0, 0));
+#pragma unroll
+            for (int q = 0; q < CH; ++q) ld2[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rr, roff[q], 0, 0));
+        } else if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
             for (int q = 0; q < CH; ++q) ld[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rr, MODE == 2 ? roff[q] : off[q], 0, 0));
         } else if constexpr (MODE == 3) {
@@ -211,8 +218,9 @@ __device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE],
         for (int q = 0; q < CH; ++q) {
             v[q] = a[e0 + q] * c.scale + bv;
             if constexpr (MODE == 1 || MODE == 2) v[q] += ld[q];
-            if constexpr (MODE == 3) v[q] *= (ld[q] > 0.f ? 1.0f : c.mask_slope);
-            if constexpr (MODE != 3) v[q] = fmaxf(v[q], v[q] * c.post_slope);   // post_slope = 1: identity (0 < slope <= 1)
+            if constexpr (MODE == 3 || MODE == 4) v[q] *= (ld[q] > 0.f ? 1.0f : c.mask_slope);
+            if constexpr (MODE == 4) v[q] += c.res_scale * ld2[q];
+            if constexpr (MODE != 3 && MODE != 4) v[q] = fmaxf(v[q], v[q] * c.post_slope);   // post_slope = 1: identity (0 < slope <= 1)
         }
         if (c.atom) {
 #pragma unroll
@@ -600,6 +608,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
     ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
     ec.mask_slope = p.mask_slope;
     ec.post_slope = p.post_slope;
+    ec.res_scale = p.res_scale;
     const bool first = kslice == 0;
     const bool has_res = p.res != nullptr && first, has_mask = p.mask_x != nullptr;   // block-uniform
     ec.atom = p.ksplit > 1;
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
     // y (and the mask, which has y's shape) in bytes: the host guarantees < 2 GiB per launch
     const unsigned ybytes = (unsigned)g.N * (unsigned)ec.Ho * (unsigned)ec.Wo * (unsigned)p.Cb * 4u;
     ec.ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
-    ec.rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, has_res ? (p.res_ups ? ybytes >> 2 : ybytes) : 0u, 0x00020000);
+    ec.rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, has_res ? ((p.res_ups || has_mask) ? ybytes >> 2 : ybytes) : 0u, 0x00020000);
     ec.rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_x, 0, has_mask ? ybytes : 0u, 0x00020000);
     auto run = [&](auto MODEC) {
         constexpr int MODE = decltype(MODEC)::value;
@@ -638,7 +647,9 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
                 }
         }
     };
-    if (has_res) {
+    if (has_res && has_mask) {     // dgrad with the pooled skip gradient folded in (gim_conv2d_dgrad_res): mask, then + res_scale * up2(res)
+        run(std::integral_constant<int, 4>());
+    } else if (has_res) {
         if (p.res_ups) run(std::integral_constant<int, 2>());
         else run(std::integral_constant<int, 1>());
     } else if (has_mask) {
@@ -854,6 +865,7 @@ __global__ __launch_bounds__(256, TM * TN <= 2 ? 3 : 2) void conv_igemm_patch_ke
     ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
     ec.mask_slope = p.mask_slope;
     ec.post_slope = p.post_slope;
+    ec.res_scale = p.res_scale;
     const bool first = kslice == 0;
     const bool has_res = p.res != nullptr && first, has_mask = p.mask_x != nullptr;
     ec.atom = p.ksplit > 1;
@@ -863,7 +875,7 @@ __global__ __launch_bounds__(256, TM * TN <= 2 ? 3 : 2) void conv_igemm_patch_ke
     ec.Ho = g.H; ec.Wo = g.W;
     const unsigned ybytes = (unsigned)g.N * (unsigned)g.H * (unsigned)g.W * (unsigned)p.Cb * 4u;
     ec.ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
-    ec.rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, has_res ? (p.res_ups ? ybytes >> 2 : ybytes) : 0u, 0x00020000);
+    ec.rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, has_res ? ((p.res_ups || has_mask) ? ybytes >> 2 : ybytes) : 0u, 0x00020000);
     ec.rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_x, 0, has_mask ? ybytes : 0u, 0x00020000);
     auto run = [&](auto MODEC) {
         constexpr int MODE = decltype(MODEC)::value;
@@ -880,7 +892,9 @@ __global__ __launch_bounds__(256, TM * TN <= 2 ? 3 : 2) void conv_igemm_patch_ke
                 epi_block<16, MODE>(ec, a, m0 + wm0 + 32 * i + 4 * h, co, cok, bv);
             }
     };
-    if (has_res) {
+    if (has_res && has_mask) {     // dgrad with the pooled skip gradient folded in (gim_conv2d_dgrad_res): mask, then + res_scale * up2(res)
+        run(std::integral_constant<int, 4>());
+    } else if (has_res) {
         if (p.res_ups) run(std::integral_constant<int, 2>());
         else run(std::integral_constant<int, 1>());
     } else if (has_mask) {
@@ -1872,11 +1886,11 @@ extern "C" int gim_conv2d_fwd(const float* x, const float* w, const float* bias,
 }
 
 static int dgrad_impl(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
-                      const gim_conv_shape* s, void* stream, bool transposed) {
+                      const gim_conv_shape* s, void* stream, bool transposed, const float* res_half = nullptr, float res_scale = 0.f) {
     int rc = check_shape(s);
     if (rc) return rc;
     GIM_CHECK_ARG(dy && w && dx, "conv dgrad: null pointer");
-    if (!transposed && s->tune_tile == 0 && s->tune_ksplit == 0 && gim_tiny_dgrad(dy, w, sigma, mask_x, dx, s, (hipStream_t)stream, t_plan_out))
+    if (!transposed && !res_half && s->tune_tile == 0 && s->tune_ksplit == 0 && gim_tiny_dgrad(dy, w, sigma, mask_x, dx, s, (hipStream_t)stream, t_plan_out))
         return t_plan_out ? GIM_OK : gim_check_launch("gim_conv2d_dgrad");
     const bool up_fold = s->ups && s->wfold;
     GIM_CHECK_ARG(!(mask_x && s->ups && !up_fold), "conv dgrad: mask_x with ups == 1 needs folded weights");
@@ -1886,9 +1900,10 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
         if (s->N > 1 && (xi > yi ? xi : yi) * s->N * sizeof(float) > BUF_MAX_BYTES) {
             gim_conv_shape a = *s, b = *s;
             a.N = s->N / 2; b.N = s->N - a.N;
-            rc = dgrad_impl(dy, w, sigma, mask_x, dx, &a, stream, transposed);
+            rc = dgrad_impl(dy, w, sigma, mask_x, dx, &a, stream, transposed, res_half, res_scale);
             if (rc) return rc;
-            return dgrad_impl(dy + a.N * yi, w, sigma, mask_x ? mask_x + a.N * xi : nullptr, dx + a.N * xi, &b, stream, transposed);
+            return dgrad_impl(dy + a.N * yi, w, sigma, mask_x ? mask_x + a.N * xi : nullptr, dx + a.N * xi, &b, stream, transposed,
+                              res_half ? res_half + a.N * (xi / 4) : nullptr, res_scale);
         }
     }
     ConvP p{};
@@ -1897,7 +1912,7 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
     // pool: dx [N,H,W,Cin] from dy [N,H/2,W/2,Cout] by input-parity classes; sub-pixel (ups+wfold): dx
     // [N,H/2,W/2,Cin] directly from dy [N,H,W,Cout] by a stride-2 gather; plain: dx at the conv's resolution
     p.g = s->pool ? geo_pc(s, 1) : (up_fold ? geo_s2(s, true) : geo_plain(s, true));
-    p.x = dy; p.w = w; p.bias = nullptr; p.sigma = sigma; p.res = nullptr; p.mask_x = mask_x; p.y = dx;
+    p.x = dy; p.w = w; p.bias = nullptr; p.sigma = sigma; p.res = res_half; p.res_scale = res_scale; p.mask_x = mask_x; p.y = dx;
     p.Ca = s->Cout; p.Cb = s->Cin; p.Cin_w = s->Cin; p.pix = s->Cout;
     p.M = p.g.N * p.g.H * p.g.W; p.Ktot = p.g.Th * p.g.Tw * s->Cout;
     {
@@ -1933,6 +1948,17 @@ static int dgrad_impl(const float* dy, const float* w, const float* sigma, const
 extern "C" int gim_conv2d_dgrad(const float* dy, const float* w, const float* sigma, const float* mask_x, float* dx,
                                 const gim_conv_shape* s, void* stream) {
     return dgrad_impl(dy, w, sigma, mask_x, dx, s, stream, false);
+}
+
+// dx = lrelu'(mask_x) * conv^T(dy, w) / sigma + res_scale * nearest_up2(res_half): the input gradient of a ResBlockDown's first conv
+// with the gradient of the block's POOLED skip path (res_half [N, H/2, W/2, Cin]; res_scale = 0.25 = the average pool's backward)
+// added in the epilogue - the fan-in that a separate pass over the full-resolution tensor did (gim_add_avgpool2_bwd).  Plain stride-1
+// convolutions, mask_x required.
+extern "C" int gim_conv2d_dgrad_res(const float* dy, const float* w, const float* sigma, const float* mask_x, const float* res_half,
+                                    float res_scale, float* dx, const gim_conv_shape* s, void* stream) {
+    GIM_CHECK_ARG(s && !s->ups && !s->pool && !s->wfold && s->H >= 2 && s->W >= 2, "conv dgrad (+ half-resolution residual): plain convolutions on maps of >= 2 x 2 only");
+    GIM_CHECK_ARG(mask_x && res_half, "conv dgrad (+ half-resolution residual): mask_x and res_half required");
+    return dgrad_impl(dy, w, sigma, mask_x, dx, s, stream, false, res_half, res_scale);
 }
 
 extern "C" int gim_conv2d_dgrad_t(const float* dy, const float* wt, const float* sigma, const float* mask_x, float* dx,

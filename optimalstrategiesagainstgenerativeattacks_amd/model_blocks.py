@@ -133,13 +133,17 @@ class SNConv2d(nn.Module):
             self._fold_cache[1].record_stream(cur)   # F was allocated on another stream: keep its memory until this one is done with it
         return self._fold_cache[1]
 
-    def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, post_slope=1.0, x_act=False):
-        """post_slope != 1: returns (y, activated) - see ops.conv2d_post_act; x_act: x was stored activated by such a producer."""
+    def forward(self, x, res=None, ups=0, pre_slope=1.0, pool=False, res_ups=False, post_slope=1.0, x_act=False, fork_pool_slope=None):
+        """post_slope != 1: returns (y, activated) - see ops.conv2d_post_act; x_act: x was stored activated by such a producer.
+        fork_pool_slope (plain convs only): returns (y, activated, avgpool2(raw x)) as one autograd node - ops.conv2d_forkpool."""
         guard = None
         if self._sn_queue:
             sigma, u_s, v_s, guard = self._sn_queue.popleft()
         else:
             sigma, u_s, v_s = ops.spectral_sigma(self.weight_orig, self.weight_u, self.weight_v, self.training)
+        if fork_pool_slope is not None:
+            assert res is None and not ups and not pool and not res_ups
+            return ops.conv2d_forkpool(x, self.weight_orig, self.bias, sigma, u_s, v_s, pre_slope, guard, post_slope, x_act, fork_pool_slope)
         wf = self.folded() if (pool or (ups and self.kernel_size > 1)) else None
         if post_slope != 1.0:
             return ops.conv2d_post_act(x, self.weight_orig, self.bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope, x_act)
@@ -328,11 +332,11 @@ class ResBlockDown(nn.Module):
         # (Round 4 tried the skip path - pool + 1x1 conv, two launches of 5-17 us - on a side stream of the lane, under conv_r1 instead of
         #  in front of it: 295-297 against 418-420 episodes/s.  One more stream per lane couples the two encoder streams that share
         #  it and adds two cross-queue waits per block and direction; profiles/r04_e_skip_stream_rejected.txt.)
-        x, pooled = ops.fork_pool(x, LRELU if x_act else 1.0)   # the two consumers of x; their gradients meet in one kernel
+        # the two readers of x - conv_r1 behind its LeakyReLU, the skip conv on the pooled RAW x - are ONE autograd node: their
+        # gradients meet in conv_r1's dgrad epilogue (ops.ConvForkPoolFn).  conv_r2 is the only reader of conv_r1's output and applies
+        # LeakyReLU to it: conv_r1 stores it activated (once per element in its epilogue); launches that split K hand back the raw tensor
+        out, act, pooled = self.conv_r1(x, pre_slope=LRELU, post_slope=LRELU, x_act=x_act, fork_pool_slope=LRELU if x_act else 1.0)
         left = self.conv_l1(pooled)
-        # conv_r2 is the only reader of conv_r1's output and applies LeakyReLU to it: conv_r1 stores it activated (once per element
-        # in its epilogue); launches that split K hand back the raw tensor
-        out, act = self.conv_r1(x, pre_slope=LRELU, post_slope=LRELU, x_act=x_act)
         if post_slope != 1.0 and ops.act_storage():
             return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True, x_act=act, post_slope=post_slope)
         return self.conv_r2(out, res=left, pre_slope=LRELU, pool=True, x_act=act), False

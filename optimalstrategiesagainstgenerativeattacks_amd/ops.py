@@ -558,7 +558,7 @@ class ConvFn(Function):
             if _TUNE_OVERRIDE:
                 sh_d = _tuned(_shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0), "dgrad",
                               (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold))
-            dx = _conv_dgrad(lib, dy, x, wp, wf, sigma, sh_d, ctx.cfg, st, w)
+            dx = _conv_dgrad(lib, dy, x, wp, wf, sigma, sh_d, ctx.cfg, st, w, getattr(ctx, "dgrad_res", None))
         want_w = ctx.needs_input_grad[1]
         want_b = has_bias and ctx.needs_input_grad[2]
         Mo = N * (H >> 1) * (W >> 1) if pool else N * H * W  # pixels of dy
@@ -629,11 +629,27 @@ def _xfold_factor(Cin, W):
     return J if (Cin <= 8 and W % J == 0 and W // J >= 1) else 0
 
 
-def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None):
+def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None, res_half=None):
     """dx = lrelu'(x) * dgrad(dy, w) / sigma  (through the pool / sub-pixel folds when the forward used them).
+    res_half [N, H/2, W/2, Cin]: the gradient w.r.t. avgpool2(x) of a second reader of x (ConvForkPoolFn): 0.25 * up2(res_half) is added -
+    in the dgrad kernel's epilogue where the launch form allows it (gim_conv2d_dgrad_res), by gim_add_avgpool2_bwd otherwise.
     With the parameter `w` given, the gradient w.r.t. IMAGES (Cin <= 8, Cout % 16 == 0) runs the k-contiguous kernel on cached
     transposed weights (gim_conv2d_dgrad_t)."""
     N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
+    if res_half is not None:
+        plain = not (ups or pool or fold) and pre_slope != 1.0 and not (w is not None and Cout % 16 == 0 and Cin <= 8 and _NARROW_DGRAD_T) \
+            and not (sh.prec == 1 and Cout % 32 == 0 and Cin >= 32)
+        if plain:
+            if _FLOPS is not None:
+                _note_conv("dgrad", cfg)
+            key = (N, H, W, Cin, Cout, KH, ups, 0, 0)
+            dx = _conv_out(sh, 1, key, tuple(x.shape), x.device)
+            check(lib.gim_conv2d_dgrad_res(_p(dy), _p(wp), _p(sigma), _p(x), _p(_req(res_half, "res_half")), 0.25, _p(dx), sh, st), "conv2d_dgrad_res")
+            return dx
+        g = _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w)
+        out = torch.empty_like(g)
+        check(lib.gim_add_avgpool2_bwd(_p(g), _p(_req(res_half, "res_half")), _p(out), N, H, W, Cin, st), "add_avgpool2_bwd")
+        return out
     if _FLOPS is not None:
         _note_conv("dgrad", cfg)
     mask = x if pre_slope != 1.0 else None
@@ -823,6 +839,68 @@ def conv2d_post_act(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, u
         act = not _splits_k(sh, 0, key)
     y = ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope if act else 1.0, x_act)
     return y, act
+
+
+class ConvForkPoolFn(Function):
+    """(y, pooled) = (ConvFn(x, w, ...), avgpool2(raw x)) for the TWO readers of a ResBlockDown's input (models/model_blocks.py:497-514:
+    conv_r1 behind a LeakyReLU, the 1x1 skip conv on the pooled input).  Forward = the two launches they always were; backward = ONE
+    dgrad launch whose epilogue adds 0.25 * up2(d pooled) to the masked conv gradient (gim_conv2d_dgrad_res) - round 3 summed the two
+    branches in a kernel of its own (gim_add_avgpool2_bwd: a read-modify-write of the block's whole input gradient, 36 launches and
+    0.58 ms per training step).  Inputs = ConvFn's, in ConvFn's order (so that ConvFn.backward's bookkeeping applies as it is), plus
+    in_slope (x stored activated: the pool inverts the LeakyReLU on the fly, see AvgPool2Fn)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope, x_act, in_slope):
+        lib = _lib.load()
+        x = _req(x, "x")
+        N, H, W, C = x.shape
+        pooled = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
+        if in_slope != 1.0:
+            check(lib.gim_avgpool2_fwd_act(_p(x), _p(pooled), N, H, W, C, in_slope, _stream()), "avgpool2_fwd_act")
+        else:
+            check(lib.gim_avgpool2_fwd(_p(x), _p(pooled), N, H, W, C, _stream()), "avgpool2_fwd")
+        y = ConvFn.forward(ctx, x, w, bias, None, sigma, u_s, v_s, 0, pre_slope, False, False, None, guard, post_slope, x_act)
+        return y, pooled
+
+    @staticmethod
+    def backward(ctx, dy, dpooled):
+        N, H, W, Cin = ctx.cfg[0], ctx.cfg[1], ctx.cfg[2], ctx.cfg[3]
+        if dy is None:      # the conv branch is unused: only the pool's backward
+            return (AvgPool2BwdFn.apply(dpooled, (N, H, W, Cin)) if dpooled is not None else None,) + (None,) * 15
+        if dpooled is not None and (torch.is_grad_enabled() or not ctx.needs_input_grad[0]):
+            # second-order pass (R1) - or no input gradient wanted at all: the unfused sum of differentiable pieces
+            grads = ConvFn.backward(ctx, dy)
+            gp = AvgPool2BwdFn.apply(dpooled, (N, H, W, Cin)) if ctx.needs_input_grad[0] else None
+            dx = gp if grads[0] is None else (grads[0] if gp is None else grads[0] + gp)
+            return (dx,) + tuple(grads[1:]) + (None,)
+        ctx.dgrad_res = dpooled
+        try:
+            grads = ConvFn.backward(ctx, dy)
+        finally:
+            ctx.dgrad_res = None
+        return tuple(grads) + (None,)
+
+
+_FUSED_FORKPOOL = os.environ.get("GIM_NO_FUSED_FORKPOOL") is None   # A/B switch (host side)
+
+
+def conv2d_forkpool(x, w, bias, sigma, u_s, v_s, pre_slope, guard, post_slope, x_act, in_slope):
+    """-> (y_stored, activated, pooled): conv2d_post_act of a plain convolution plus avgpool2 of its (raw) input, as ONE autograd node
+    whose backward folds the pooled branch's gradient into the dgrad epilogue (ConvForkPoolFn)."""
+    act = False
+    N, H, W, Cin = x.shape
+    Cout, KH = w.shape[0], w.shape[2]
+    if _ACT_STORAGE and post_slope != 1.0:
+        key = (N, H, W, Cin, Cout, KH, 0, 0, 0)
+        sh = _tuned(_shape(N, H, W, Cin, Cout, KH, 0, pre_slope), "fwd", key)
+        act = not _splits_k(sh, 0, key)
+    ps = post_slope if act else 1.0
+    if _FUSED_FORKPOOL and x.requires_grad and torch.is_grad_enabled():
+        y, pooled = ConvForkPoolFn.apply(x, w, bias, None, sigma, u_s, v_s, 0, pre_slope, False, False, None, guard, ps, x_act, in_slope)
+    else:
+        xa, pooled = fork_pool(x, in_slope)
+        y = ConvFn.apply(xa, w, bias, None, sigma, u_s, v_s, 0, pre_slope, False, False, None, guard, ps, x_act)
+    return y, act, pooled
 
 
 def linear(x, w, bias=None, pre_slope=1.0):

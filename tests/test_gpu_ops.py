@@ -286,6 +286,43 @@ def test_image_layer_rows_form_through_the_gradient_bucket(N, Cin, Cout, K, H, s
     assert relerr((bg.grad - pre).double().cpu(), b.grad) < TOL, "db"
 
 
+@pytest.mark.parametrize("N,Cin,Cout,K,H,x_act", [(3, 32, 64, 3, 16, False), (2, 64, 128, 3, 32, True), (2, 16, 48, 3, 4, False), (5, 128, 128, 3, 2, True),
+                                                 (2, 3, 32, 3, 16, False), (2, 6, 64, 9, 16, False), (3, 48, 32, 1, 8, False)])
+def test_conv_with_pooled_skip_reader_one_autograd_node(N, Cin, Cout, K, H, x_act):
+    """ops.conv2d_forkpool: y = conv(lrelu(x)) and pooled = avgpool2(x) as ONE node whose backward adds the pooled branch's gradient in
+    the dgrad epilogue (gim_conv2d_dgrad_res; patch-resident and tap-major kernels, split-K maps) - or, where the dgrad takes another
+    launch form (image layers: x-fold), behind it - against fp64 autograd, and against the unfused pair of round 3."""
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
+    tag = "cfp%s" % ((N, Cin, Cout, K, H, x_act),)
+    slope = 0.2
+    x = T(pf.normal(tag + "x", (N, Cin, H, H))).requires_grad_()
+    w = T(pf.normal(tag + "w", (Cout, Cin, K, K)) / np.sqrt(Cin * K * K)).requires_grad_()
+    b = T(pf.normal(tag + "b", (Cout,))).requires_grad_()
+    y = F.conv2d(F.leaky_relu(x, slope), w / 1.4, b, padding=(K - 1) // 2)
+    pooled = F.avg_pool2d(x, 2)
+    r1, r2 = T(pf.uniform(tag + "r1", tuple(y.shape))), T(pf.uniform(tag + "r2", tuple(pooled.shape)))
+    ((y * r1).sum() + (pooled * r2).sum()).backward()
+    sg = torch.tensor([1.4], device=dev())
+    u0, v0 = torch.zeros(Cout, device=dev()), torch.zeros(Cin * K * K, device=dev())
+    outs = []
+    for fused in (True, False):
+        prev = ops._FUSED_FORKPOOL
+        ops._FUSED_FORKPOOL = fused
+        try:
+            xin = nhwc(F.leaky_relu(x, slope) if x_act else x).requires_grad_()
+            wg = cl_weight(w)
+            bg = b.detach().float().to(dev()).requires_grad_()
+            yg, act, pg = ops.conv2d_forkpool(xin, wg, bg, sg, u0, v0, slope, None, 1.0, x_act, slope if x_act else 1.0)
+            assert relerr(nchw(yg), y) < TOL and relerr(nchw(pg), pooled) < TOL and not act
+            ((yg * nhwc(r1)).sum() + (pg * nhwc(r2)).sum()).backward()
+        finally:
+            ops._FUSED_FORKPOOL = prev
+        assert relerr(nchw(xin.grad), x.grad) < TOL, ("dx", fused)
+        assert relerr(wg.grad.double().cpu(), w.grad) < TOL and relerr(bg.grad.double().cpu(), b.grad) < TOL, fused
+        outs.append(xin.grad)
+    assert relerr(outs[0], outs[1]) < 1e-6
+
+
 def test_linear_fwd_bwd():
     from optimalstrategiesagainstgenerativeattacks_amd import ops
     for rows, din, dout, slope in [(5, 6, 10, 1.0), (80, 512, 1024, 0.2), (16, 320, 1, 0.2), (240, 96, 64, 1.0)]:
