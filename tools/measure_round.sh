@@ -2,6 +2,8 @@
 # End-of-iteration measurement set on the GPU box (one gpurun call):  tools/measure_round.sh <tag>
 #   full GPU suite, default bench (traffic + CPU baseline), other workloads, rocprofv3 kernel stats, per-layer table, PMC of the
 #   dominant conv kernels.  Everything lands in gpurun_out/measure_<tag>/.
+# the HIP runtime reads this when it starts - under rocprofv3 --pmc the profiler initialises the GPU before python imports the package, so set it here
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 tag=$1
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/measure_$tag

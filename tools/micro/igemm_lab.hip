@@ -251,6 +251,170 @@ __global__ __launch_bounds__(256, lab_lds_bytes(BM, BN, KB, VAR) <= 40960 ? 4 : 
     }
 }
 
+// VAR 3: PERSISTENT workgroups.  The grid is (compute units x 4) workgroups; each walks output tiles
+// tile, tile + grid, ... of the staged loop (VAR 0).  PREFETCH: in the LAST K step of a tile the workgroup sets up the next tile's
+// addresses and issues ITS first operand loads, which land in LDS behind that step's MFMAs - the next tile's K loop starts without a
+// prologue; the epilogue (accumulators copied out first) follows in program order.  Without PREFETCH the loop only removes the
+// workgroup launches.  K / KB must be even (every tile then starts on LDS buffer 0: compile-time buffers in the loop).
+template <int BM, int BN, int KB, bool PREFETCH>
+__global__ __launch_bounds__(256, 4) void lab_persist_kernel(const LabP p, int tiles_m, int ntiles) {
+    constexpr int LDK = KB + 4;
+    constexpr int QPR = KB / 4, RP = 256 / QPR, A_ROWS = BM / RP, B_ROWS = BN / RP;
+    constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;
+    static_assert(BM == 64 && BN == 64, "one 32 x 32 accumulator per wave");
+    __shared__ __attribute__((aligned(1024))) float lds[2 * A_SZ + 2 * B_SZ];
+    float* As = lds;
+    float* Bs = lds + 2 * A_SZ;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int arow = t / QPR, aq = (t % QPR) * 4;
+    const int K = p.T * p.Ca, nk = K / KB;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xFFFFFFFFu, 0x00020000);
+    unsigned a_base[A_ROWS], a_cur[A_ROWS], b_voff[B_ROWS];
+    int k_c0 = 0, k_tap = 0, m0 = 0, n0 = 0;
+    auto set_tap = [&](int tap) {
+        const unsigned off = (unsigned)(((tap / 3) * p.Wimg + (tap % 3)) * p.Ca * 4);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) a_cur[i] = a_base[i] + off;
+    };
+    auto setup = [&](int tile) {
+        m0 = (tile % tiles_m) * BM;
+        n0 = (tile / tiles_m) * BN;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) a_base[i] = (unsigned)((min(m0 + arow + RP * i, p.M - 1) * p.Ca + aq) * 4);
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) b_voff[i] = (unsigned)((min(n0 + arow + RP * i, p.N - 1) * K + aq) * 4);
+        k_c0 = 0; k_tap = 0;
+        set_tap(0);
+    };
+    f32x4 ra[A_ROWS], rb[B_ROWS];
+    auto load_tiles = [&]() {
+        const unsigned sa = (unsigned)(k_c0 * 4), sb = (unsigned)((k_tap * p.Ca + k_c0) * 4);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) ra[i] = buf_load4(rx, a_cur[i], sa);
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_voff[i], sb);
+        k_c0 += KB;
+        if (k_c0 == p.Ca) { k_c0 = 0; ++k_tap; set_tap(k_tap); }
+    };
+    const bool has_act = p.slope != 1.0f;
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            if (has_act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.slope, p.pos_inf);
+            }
+            *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (arow + RP * i) * LDK + aq]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + (arow + RP * i) * LDK + aq]) = rb[i];
+    };
+    const int r = lane & 31, h = lane >> 5;
+    const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto mfmas = [&](auto BUFC) {
+        constexpr int buf = decltype(BUFC)::value;
+        const float* Ab = As + buf * A_SZ;
+        const float* Bb = Bs + buf * B_SZ;
+        f32x4 a[KB / 8], b[KB / 8];
+#pragma unroll
+        for (int kk = 0; kk < KB / 8; ++kk) {
+            a[kk] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + r) * LDK + 8 * kk + 4 * h]);
+            b[kk] = *reinterpret_cast<const f32x4*>(&Bb[(wn0 + r) * LDK + 8 * kk + 4 * h]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KB / 8; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][e], b[kk][e], acc, 0, 0, 0);
+    };
+    auto kstep = [&](auto BUFC) {      // a step with a successor INSIDE its tile
+        constexpr int buf = decltype(BUFC)::value;
+        load_tiles();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(BUFC);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1);
+        __syncthreads();
+    };
+    int tile = blockIdx.x;
+    setup(tile);
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+    for (;;) {
+        for (int ks = 0; ks + 2 < nk; ks += 2) {
+            kstep(std::integral_constant<int, 0>());
+            kstep(std::integral_constant<int, 1>());
+        }
+        kstep(std::integral_constant<int, 0>());
+        // last K step of the tile (LDS buffer 1)
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+        const int em0 = m0, en0 = n0;
+        if (PREFETCH && has_next) {
+            setup(next);
+            load_tiles();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(std::integral_constant<int, 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        if (PREFETCH && has_next) store_tiles(0);
+        __syncthreads();
+        // epilogue of the finished tile
+        f32x16 out = acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const int col = en0 + wn0 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = em0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row < p.M && col < p.N) p.y[(long long)row * p.N + col] = out[e];
+        }
+        if (!has_next) break;
+        if (!PREFETCH) {
+            setup(next);
+            load_tiles();
+            store_tiles(0);
+            __syncthreads();
+        }
+        tile = next;
+    }
+}
+
+template <int KB, bool PREFETCH>
+static void run_persist(LabP p, const std::vector<double>& ref, int ref_rows, int wg_per_cu) {
+    constexpr int BM = 64, BN = 64;
+    if ((p.T * p.Ca / KB) % 2 != 0 || p.Ca % KB != 0) return;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    // wg_per_cu 0: the balanced grid - every workgroup walks the same number of tiles (ceil(tiles / 1024) of them)
+    const int rounds = (ntiles + 1023) / 1024;
+    const int grid = wg_per_cu == 0 ? (ntiles + rounds - 1) / rounds : (ntiles < 256 * wg_per_cu ? ntiles : 256 * wg_per_cu);
+    CK(hipMemset(p.y, 0xFF, (size_t)p.M * p.N * 4));
+    hipLaunchKernelGGL((lab_persist_kernel<BM, BN, KB, PREFETCH>), dim3(grid), dim3(256), 0, 0, p, tiles_m, ntiles);
+    CK(hipDeviceSynchronize());
+    std::vector<float> y((size_t)ref_rows * p.N);
+    CK(hipMemcpy(y.data(), p.y, y.size() * 4, hipMemcpyDeviceToHost));
+    double emax = 0, rmax = 0;
+    for (size_t i = 0; i < y.size(); ++i) { emax = fmax(emax, fabs((double)y[i] - ref[i])); rmax = fmax(rmax, fabs(ref[i])); }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 20;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((lab_persist_kernel<BM, BN, KB, PREFETCH>), dim3(grid), dim3(256), 0, 0, p, tiles_m, ntiles);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((lab_persist_kernel<BM, BN, KB, PREFETCH>), dim3(grid), dim3(256), 0, 0, p, tiles_m, ntiles);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    printf("%-44s %4dx%-3d KB%-2d  %8.4f ms %7.1f TF  err %.1e  (%d workgroups for %d tiles)\n",
+           PREFETCH ? "persistent + cross-tile prefetch" : "persistent (no prefetch)", BM, BN, KB, ms, 2.0 * p.M * p.N * (double)p.T * p.Ca / ms / 1e9, emax / rmax, grid, ntiles);
+}
+
 // VAR 2: input patch resident in LDS.  The 3 x 3 taps of a tile of BM consecutive output rows read the BM + 2 * WIMG + 2 input rows
 // m0 .. m0 + BM + 2 * WIMG + 1: they are loaded ONCE per 16-channel chunk (K order: channel chunk outer, taps inner) and every tap's
 // A fragment is the same LDS image at a compile-time row offset (ds_read immediate) - 9x fewer activation loads, ds_writes,
@@ -528,6 +692,12 @@ int main(int argc, char** argv) {
                 run<64, 64, 1, 1, 32, 0, false>(p, "staged", ref, ref_rows);
                 if (s.N >= 128) run<64, 128, 1, 2, 16, 0, false>(p, "staged", ref, ref_rows);
                 run<128, 64, 2, 1, 16, 0, false>(p, "staged", ref, ref_rows);
+                if (!p.oob_test) {
+                    run_persist<32, false>(p, ref, ref_rows, 4);
+                    run_persist<32, true>(p, ref, ref_rows, 4);
+                    run_persist<32, true>(p, ref, ref_rows, 0);
+                    run_persist<32, true>(p, ref, ref_rows, 2);
+                }
                 if (round == 0) {
                     run<64, 64, 1, 1, 32, 0, true>(p, "staged, STAMPED", ref, ref_rows);
                     if (s.N >= 128) run<64, 128, 1, 2, 16, 0, true>(p, "staged, STAMPED", ref, ref_rows);

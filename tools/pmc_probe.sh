@@ -1,5 +1,7 @@
 #!/bin/bash
 # PMC passes (one counter set per run, kernel-trace only) on single conv shapes.  usage: tools/pmc_probe.sh <outdir>
+# the HIP runtime reads this when it starts - under rocprofv3 --pmc the profiler initialises the GPU before python imports the package, so set it here
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 out=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,8 @@
 #!/bin/bash
 # L2-miss traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the dominant conv shapes, one launch form per run:
 #   tools/traffic_per_layer.sh <outdir under gpurun_out>;  summary: python tools/traffic_per_layer.py gpurun_out/<outdir>
+# the HIP runtime reads this when it starts - under rocprofv3 --pmc the profiler initialises the GPU before python imports the package, so set it here
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 out=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
