@@ -192,6 +192,17 @@ int gim_conv2d_fwd_rows(const float* xp, const float* wp, const float* bias, con
                         float* y, const gim_conv_shape* shape, void* stream);
 int gim_conv2d_wgrad_rows_acc(const float* dy, const float* xp, float* acc, float* bias_acc, const gim_conv_shape* shape, void* stream);
 
+/* Sub-pixel convolution to <= 4 output channels (the generator's last layer, 9x9 64 -> 3 behind nn.Upsample: models/gim_img_models.py:187-193
+ * -> models/model_blocks.py:752-773): for KH = 5, 9, 13 the four output-parity classes read the same ((KH+1)/2)^2 window of the
+ * low-resolution input, so they stack into ONE plain ((KH+1)/2)-tap convolution to 4 * Cout channels (gim_conv2d_fwd on wm, no bias)
+ * followed by a depth-to-space copy that adds the bias.  Forward only: the gradients run the sub-pixel forms of gim_conv2d_dgrad / wgrad.
+ *   gim_conv2d_pack_subpixel_weights: wm [4 Cout][(KH+1)/2][(KH+1)/2][Cin] from the folded taps wf [Cout][KH+1][KH+1][Cin]
+ *     (gim_conv2d_fold_weights), row (2 py + px) * Cout + co = output parity (py, px) of channel co.
+ *   gim_depth_to_space2: y [N, 2 Hs, 2 Ws, C][n][2 h + py][2 w + px][c] = y4 [N, Hs, Ws, 4 C][n][h][w][(2 py + px) * C + c] + bias[c],
+ *     stored as lrelu(., post_slope) when post_slope != 1 (the activated-output convention of gim_conv_shape.post_slope). */
+int gim_conv2d_pack_subpixel_weights(const float* wf, float* wm, int Cout, int Cin, int KH, void* stream);
+int gim_depth_to_space2(const float* y4, const float* bias, float* y, int N, int Hs, int Ws, int C, float post_slope, void* stream);
+
 /* Introspection (tests, tools/conv_autotune.py): the launch an entry point would make for `shape`, nothing is launched.
  *   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
  *   out[8] = {1 if a row of the compiled-in per-shape launch table matched, tile rows, tile columns, split-K factor

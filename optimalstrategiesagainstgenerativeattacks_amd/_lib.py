@@ -91,6 +91,8 @@ SIGNATURES = {
     "gim_spin": [c_int, P],
     "gim_pad_image": [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P],
     "gim_conv2d_pack_rows_weights": [P, P, c_int, c_int, c_int, P],
+    "gim_conv2d_pack_subpixel_weights": [P, P, c_int, c_int, c_int, P],
+    "gim_depth_to_space2": [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "gim_conv2d_fwd_rows": [P, P, P, P, P, P, SP, P],
     "gim_conv2d_wgrad_rows_acc": [P, P, P, P, SP, P],
     "gim_version": [],

@@ -2061,6 +2061,36 @@ extern "C" int gim_pad_image(const float* x, float* xp, int N, int H, int W, int
     return gim_check_launch("gim_pad_image");
 }
 
+// -------------------------------------------------------------------------------------------------
+// Sub-pixel convolution to <= 4 output channels (the generators' 9x9 64->3 image layer): for K = 5, 9, 13 ((K - 1) / 2 even) the four
+// output-parity classes of conv_KxK(up2(x)) gather the SAME ((K+1)/2)^2 window of the low-resolution x (offset -(K-1)/4), each with
+// its own strided subset of the folded taps F.  As four classes of a 3-column GEMM they fill 3 of the 16 columns of the narrowest MFMA
+// tile (0.19 ms, 0.11 of peak); stacked, they are ONE plain ((K+1)/2)-tap convolution to 4 * Cout channels - the same executed FLOPs on
+// 12 of 16 columns - followed by a depth-to-space copy (gim_depth_to_space2, which also adds the bias):
+//   WM[(2 py + px) * Cout + co][ta][tb][ci] = F[co][1 - py + 2 ta][1 - px + 2 tb][ci]
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_subpixel_weights_kernel(const float* __restrict__ f, float* __restrict__ wm, int Cout, int Cin, int K) {
+    const int KF = K + 1, T = KF / 2;
+    const int total = 4 * Cout * T * T * Cin;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int ci = i % Cin;
+        int r = i / Cin;
+        const int tb = r % T; r /= T;
+        const int ta = r % T; r /= T;
+        const int co = r % Cout, cls = r / Cout;
+        const int py = cls >> 1, px = cls & 1;
+        wm[i] = f[((co * KF + 1 - py + 2 * ta) * KF + 1 - px + 2 * tb) * Cin + ci];
+    }
+}
+
+extern "C" int gim_conv2d_pack_subpixel_weights(const float* wf, float* wm, int Cout, int Cin, int KH, void* stream) {
+    GIM_CHECK_ARG(wf && wm && Cout > 0 && Cin > 0 && KH >= 5 && (KH & 3) == 1, "pack_subpixel_weights: KH must be 5, 9, 13, ...");
+    const int T = (KH + 1) / 2, total = 4 * Cout * T * T * Cin;
+    hipLaunchKernelGGL(pack_subpixel_weights_kernel, dim3((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024), dim3(256), 0, (hipStream_t)stream,
+                       wf, wm, Cout, Cin, KH);
+    return gim_check_launch("gim_conv2d_pack_subpixel_weights");
+}
+
 static int rows_shape_ok(const gim_conv_shape* s) {
     int rc = check_shape(s);
     if (rc) return rc;

@@ -903,6 +903,31 @@ extern "C" int gim_colsum_acc(const float* x, float* out, float* scratch, int64_
     return gim_check_launch("gim_colsum_acc");
 }
 
+// ---------------------------------------------------------------- depth to space
+// y[n][2 h + py][2 w + px][c] = lrelu(y4[n][h][w][(2 py + px) * C + c] + bias[c], post_slope): un-stacks the four output-parity classes of the merged
+// sub-pixel convolution (gim_conv2d_pack_subpixel_weights in conv_igemm.hip)
+__global__ __launch_bounds__(256) void depth_to_space2_kernel(const float* __restrict__ y4, const float* __restrict__ bias, float* __restrict__ y,
+                                                              int N, int Hs, int Ws, int C, float post_slope) {
+    const long long total = (long long)N * Hs * Ws * 4 * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int cls = (int)(r & 3); r >>= 2;
+        const int w = (int)(r % Ws); r /= Ws;
+        const int h = (int)(r % Hs);
+        const long long n = r / Hs;
+        const float v = y4[i] + (bias ? bias[c] : 0.f);
+        y[((n * 2 * Hs + 2 * h + (cls >> 1)) * 2 * Ws + 2 * w + (cls & 1)) * C + c] = fmaxf(v, v * post_slope);
+    }
+}
+extern "C" int gim_depth_to_space2(const float* y4, const float* bias, float* y, int N, int Hs, int Ws, int C, float post_slope, void* stream) {
+    GIM_CHECK_ARG(y4 && y && N > 0 && Hs > 0 && Ws > 0 && C > 0 && post_slope > 0.f && post_slope <= 1.f, "depth_to_space2: bad args");
+    const long long total = (long long)N * Hs * Ws * 4 * C;
+    hipLaunchKernelGGL(depth_to_space2_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       y4, bias, y, N, Hs, Ws, C, post_slope);
+    return gim_check_launch("gim_depth_to_space2");
+}
+
 // ---------------------------------------------------------------- stream self-check
 // One wave that keeps a compute unit busy for `usec` microseconds of the constant 100 MHz wall clock (s_memrealtime), capped at
 // 5 ms: every wave reaches the exit.  ops.stream_concurrency_check launches one per engine stream at the same time: streams that

@@ -503,7 +503,8 @@ class ConvFn(Function):
         _tuned(sh, "fwd", key)
         # post_slope != 1: store lrelu(y) for a consumer that is the ONLY reader of y and runs with x_act.  conv2d_post_act has
         # resolved it (1.0 when the launch splits K: the slices combine by addition); a split-K launch refuses it here
-        if post_slope != 1.0:
+        merged = _merged_subpixel(x, w, ups, res, sh)
+        if post_slope != 1.0 and not merged:
             if x.dim() != 4 or _splits_k(sh, 0, key):
                 raise RuntimeError("conv: an activated output (post_slope) cannot be combined with a split-K launch or a linear layer")
             sh.post_slope = post_slope
@@ -520,6 +521,19 @@ class ConvFn(Function):
             sh.tune_ksplit = 1      # one K slice: these layers have >= 10^5 output pixels; keeps an activated output (post_slope) legal
             y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
             check(lib.gim_conv2d_fwd_rows(_p(xp), _p(wrows), _p(bias), _p(sigma), _p(res), _p(y), sh, _stream()), "conv2d_fwd_rows")
+        elif merged:
+            # the generator's last layer (9x9 64->3 behind the upsample): the four output-parity classes as ONE plain 5-tap convolution
+            # to 4 * Cout channels + a depth-to-space copy (include/gim_hip.h gim_conv2d_pack_subpixel_weights); gradients: the sub-pixel forms
+            if wf is None:
+                wf = _folded(wp, Cout, Cin, KH)
+            wm = _transposed(lib, w, wf, Cout, Cin, KH, subpix=True)
+            shm = _shape(N, Hs, Ws, Cin, 4 * Cout, (KH + 1) // 2, 0, 1.0 if x_act else pre_slope, 0, 0, 0)
+            keym = (N, Hs, Ws, Cin, 4 * Cout, (KH + 1) // 2, 0, 0, 0)
+            _tuned(shm, "fwd", keym)
+            y4 = _conv_out(shm, 0, keym, (N, Hs, Ws, 4 * Cout), x.device)
+            check(lib.gim_conv2d_fwd(_p(x), _p(wm), None, _p(sigma), None, _p(y4), shm, _stream()), "conv2d_fwd")
+            y = torch.empty((N, H, W, Cout), device=x.device, dtype=torch.float32)
+            check(lib.gim_depth_to_space2(_p(y4), _p(bias), _p(y), N, Hs, Ws, Cout, post_slope, _stream()), "depth_to_space2")
         else:
             y = _conv_out(sh, 0, key, (N, Cout) if x.dim() == 2 else (N, Ho, Wo, Cout), x.device)
             if fold and wf is None:
@@ -583,19 +597,28 @@ class ConvFn(Function):
 
 _ACT_STORAGE = os.environ.get("GIM_NO_ACT_STORAGE") is None   # A/B switch (host side)
 _ROWS_FORM = os.environ.get("GIM_NO_ROWS_FORM") is None   # A/B switch (host side): row-contiguous K for the image layers
+_MERGED_SUBPIXEL = os.environ.get("GIM_NO_MERGED_SUBPIXEL") is None   # A/B switch (host side): stacked parity classes for the 9x9 64->3 layer
+
+
+def _merged_subpixel(x, w, ups, res, sh):
+    """Does this forward run as the stacked-parity-class convolution (ConvFn.forward; include/gim_hip.h gim_conv2d_pack_subpixel_weights)?"""
+    KH = w.shape[2] if w.dim() == 4 else 1
+    return bool(_MERGED_SUBPIXEL and ups and KH >= 5 and (KH & 3) == 1 and w.shape[0] <= 4 and x.dim() == 4 and res is None and sh.tune_tile == 0)
+
 _NARROW_DGRAD_T = os.environ.get("GIM_NO_NARROW_DGRAD_T") is None   # A/B switch (host side)
 _NARROW_XFOLD = os.environ.get("GIM_NO_NARROW_XFOLD") is None   # A/B switch (host side)
 _WT_CACHE = {}   # (weight data_ptr, taps per dim) -> (version key, WT, ready event, stream, weakref to the parameter)
 
 
-def _transposed(lib, w, wk, Cout, Cin, KF, xfold=0, rows=False):
+def _transposed(lib, w, wk, Cout, Cin, KF, xfold=0, rows=False, subpix=False):
     """WT[Cin][KF][KF][Cout] of the (plain or folded) weights `wk` of parameter `w` - or, xfold = J, the x-folded
     WX[J * Cin][KF][KF + J - 1][Cout] of gim_conv2d_xfold_weights; or, rows, the row-padded WP[Cout][KF][KF * Cin -> 16] of
-    gim_conv2d_pack_rows_weights - recomputed only when the weights changed (autograd version
+    gim_conv2d_pack_rows_weights; or, subpix (wk = the folded taps, KF = the conv's K), the stacked parity classes
+    WM[4 Cout][(KF+1)/2][(KF+1)/2][Cin] of gim_conv2d_pack_subpixel_weights - recomputed only when the weights changed (autograd version
     counter for torch-side writes, optim.weights_epoch for the fused Adam kernel)."""
     from . import optim
     key = (w._version, optim.weights_epoch(w))
-    slot = (w.data_ptr(), KF, "rows" if rows else xfold)
+    slot = (w.data_ptr(), KF, "rows" if rows else ("subpix" if subpix else xfold))
     ent = _WT_CACHE.get(slot)
     raw = _stream()
     if ent is None or ent[0] != key or ent[4]() is not w:
@@ -603,6 +626,9 @@ def _transposed(lib, w, wk, Cout, Cin, KF, xfold=0, rows=False):
         if rows:
             wt = torch.empty(Cout * KF * ((KF * Cin + 15) & ~15), device=wk.device, dtype=torch.float32)
             check(lib.gim_conv2d_pack_rows_weights(_p(wk), _p(wt), Cout, Cin, KF, raw), "pack_rows_weights")
+        elif subpix:
+            wt = torch.empty(4 * Cout * ((KF + 1) // 2) ** 2 * Cin, device=wk.device, dtype=torch.float32)
+            check(lib.gim_conv2d_pack_subpixel_weights(_p(wk), _p(wt), Cout, Cin, KF, raw), "pack_subpixel_weights")
         elif xfold:
             wt = torch.empty(xfold * Cin * KF * (KF + xfold - 1) * Cout, device=wk.device, dtype=torch.float32)
             check(lib.gim_conv2d_xfold_weights(_p(wk), _p(wt), Cout, Cin, KF, xfold, raw), "xfold_weights")
@@ -836,7 +862,7 @@ def conv2d_post_act(x, w, bias=None, res=None, sigma=None, u_s=None, v_s=None, u
         fold = 1 if (pool or (ups and KH > 1)) else 0
         key = (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold)
         sh = _tuned(_shape(N, H, W, Cin, Cout, KH, ups, pre_slope, 1 if pool else 0, fold, 1 if res_ups else 0), "fwd", key)
-        act = not _splits_k(sh, 0, key)
+        act = _merged_subpixel(x, w, ups, res, sh) or not _splits_k(sh, 0, key)   # (the stacked form activates in its depth-to-space copy)
     y = ConvFn.apply(x, w, bias, res, sigma, u_s, v_s, ups, pre_slope, pool, res_ups, wf, guard, post_slope if act else 1.0, x_act)
     return y, act
 

@@ -165,6 +165,48 @@ def test_tiny_image_conv_direct_kernels(case):
         assert relerr(nchw(rg.grad), res.grad) < TOL, "dres"
 
 
+@pytest.mark.parametrize("N,Cin,Cout,K,H,slope,post", [(3, 64, 3, 9, 32, 0.2, 0.2), (2, 16, 4, 5, 8, 1.0, 1.0), (2, 32, 1, 9, 16, 0.2, 1.0),
+                                                     (5, 24, 3, 13, 8, 0.2, 0.2), (1, 64, 3, 9, 2, 0.2, 1.0)])
+def test_subpixel_conv_to_image_channels_stacked_classes(N, Cin, Cout, K, H, slope, post):
+    """conv_KxK(up2(x)) to <= 4 channels, K = 5, 9, 13 (the generator's last 9x9 64->3 layer, models/gim_img_models.py:187-193): the
+    forward runs the four output-parity classes stacked into one plain convolution + a depth-to-space copy
+    (gim_conv2d_pack_subpixel_weights, gim_depth_to_space2), optionally storing the activated output; gradients: the sub-pixel forms."""
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
+    tag = "subpix%s" % ((N, Cin, Cout, K, H),)
+    Hs = H // 2
+    x = T(pf.normal(tag + "x", (N, Cin, Hs, Hs))).requires_grad_()
+    w = T(pf.normal(tag + "w", (Cout, Cin, K, K)) / np.sqrt(Cin * K * K)).requires_grad_()
+    b = T(pf.normal(tag + "b", (Cout,))).requires_grad_()
+    sig = 1.3
+    xa = F.leaky_relu(x, slope) if slope != 1.0 else x
+    y = F.conv2d(go.upsample2(xa), w / sig, b, padding=(K - 1) // 2)
+    r = T(pf.uniform(tag + "dy", tuple(y.shape)))
+    (y * r).sum().backward()
+
+    xg, wg = nhwc(x).requires_grad_(), cl_weight(w)
+    bg = b.detach().float().to(dev()).requires_grad_()
+    sg = torch.tensor([sig], device=dev())
+    u0, v0 = torch.zeros(Cout, device=dev()), torch.zeros(Cin * K * K, device=dev())
+    sh = ops._shape(N, H, H, Cin, Cout, K, 1, slope, 0, 1, 0)
+    assert ops._merged_subpixel(xg, wg, 1, None, sh)
+    yg, act = ops.conv2d_post_act(xg, wg, bg, None, sg, u0, v0, 1, slope, post_slope=post)
+    assert act == (post != 1.0)
+    y_stored = F.leaky_relu(y, post) if act else y
+    assert relerr(nchw(yg), y_stored.detach()) < TOL
+    (yg * nhwc(r)).sum().backward()      # ConvFn's backward is that of the RAW output (its consumer un-does the activation)
+    assert relerr(nchw(xg.grad), x.grad) < TOL, "dx"
+    assert relerr(wg.grad.double().cpu(), w.grad) < TOL, "dw"
+    assert relerr(bg.grad.double().cpu(), b.grad) < TOL, "db"
+    # the four-class launch it replaces computes the same numbers
+    old = ops._MERGED_SUBPIXEL
+    ops._MERGED_SUBPIXEL = False
+    try:
+        y2 = ops.conv2d(xg.detach(), wg.detach(), bg.detach(), None, sg, None, None, 1, slope)
+    finally:
+        ops._MERGED_SUBPIXEL = old
+    assert relerr(nchw(y2), y.detach()) < TOL
+
+
 @pytest.mark.parametrize("case", POOL_CASES, ids=[str(c) for c in POOL_CASES])
 def test_conv2d_pool_fold(case):
     """avgpool2(conv(lrelu(x))) + res as ONE stride-2 convolution with folded weights: fwd, dx, dw, db, dres."""

@@ -90,6 +90,18 @@ def main():
                 lib.gim_pad_image(x.data_ptr(), xp.data_ptr(), N, H, W, Cin, pad, slope, st)
                 lib.gim_conv2d_fwd_rows(xp.data_ptr(), wr.data_ptr(), None, None, None, y.data_ptr(), shr, st)
             t_f = time_ms(fwd_rows)
+        elif ops._MERGED_SUBPIXEL and ups and fold and KH >= 5 and (KH & 3) == 1 and Cout <= 4:
+            # as ops.ConvFn: the four parity classes stacked into one plain convolution + the depth-to-space copy
+            T = (KH + 1) // 2
+            wm = torch.empty(4 * Cout * T * T * Cin, device=dev)
+            lib.gim_conv2d_pack_subpixel_weights(w.data_ptr(), wm.data_ptr(), Cout, Cin, KH, st)
+            y4 = torch.empty(N, H >> 1, W >> 1, 4 * Cout, device=dev)
+            shm = _lib.GimConvShape(N, H >> 1, W >> 1, Cin, 4 * Cout, T, 0, slope, 0, 0, 0)
+
+            def fwd_stacked():
+                lib.gim_conv2d_fwd(x.data_ptr(), wm.data_ptr(), None, None, None, y4.data_ptr(), shm, st)
+                lib.gim_depth_to_space2(y4.data_ptr(), None, y.data_ptr(), N, H >> 1, W >> 1, Cout, 1.0, st)
+            t_f = time_ms(fwd_stacked)
         else:
             t_f = time_ms(lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st))
         J = ops._xfold_factor(Cin, W) if (KH >= 3 and not (ups or pool or fold) and Cout % 16 == 0 and ops._NARROW_XFOLD) else 0
