@@ -415,6 +415,153 @@ static void run_persist(LabP p, const std::vector<double>& ref, int ref_rows, in
            PREFETCH ? "persistent + cross-tile prefetch" : "persistent (no prefetch)", BM, BN, KB, ms, 2.0 * p.M * p.N * (double)p.T * p.Ca / ms / 1e9, emax / rmax, grid, ntiles);
 }
 
+// VAR 4: WAVE-SPECIALISED workgroups.  4 MFMA waves (one 32 x 32 accumulator each, 64 x 64 tile) that only
+// ds_read and multiply, plus NL loader waves (NL = 1: A and B tiles; NL = 2: one each) that issue every global load, the activation and
+// every ds_write of the workgroup: an MFMA wave's issue queue then holds nothing that has to wait for a gap between other waves' MFMAs
+// (the fp32 MFMA occupies the vector ALUs).  One barrier per K step for all waves; two LDS buffers; the loader holds ONE step in
+// registers, loaded a full barrier interval before it is written.  K / KB even.
+template <int KB, int NL>
+__global__ __launch_bounds__(256 + 64 * NL, 4) void lab_ws_kernel(const LabP p) {
+    constexpr int BM = 64, BN = 64, LDK = KB + 4, A_SZ = BM * LDK, B_SZ = BN * LDK;
+    constexpr int QPR = KB / 4, RPW = 64 / QPR, NR = 64 / RPW;    // a loader wave covers RPW rows per pass, NR passes per tile
+    __shared__ __attribute__((aligned(1024))) float lds[2 * A_SZ + 2 * B_SZ];
+    float* As = lds;
+    float* Bs = lds + 2 * A_SZ;
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int K = p.T * p.Ca, nk = K / KB;
+    if (wv >= 4) {
+        // ---------------- loader
+        const bool doA = NL == 1 || wv == 4, doB = NL == 1 || wv == 5;
+        const int lrow = lane / QPR, aq = (lane % QPR) * 4;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xFFFFFFFFu, 0x00020000);
+        unsigned a_base[NR], a_cur[NR], b_voff[NR];
+        bool a_pad[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int m = min(m0 + lrow + RPW * i, p.M - 1);
+            a_base[i] = (unsigned)((m * p.Ca + aq) * 4);
+            a_pad[i] = p.oob_test && (m % 5 == 0);
+            a_cur[i] = a_base[i];
+            b_voff[i] = (unsigned)((min(n0 + lrow + RPW * i, p.N - 1) * K + aq) * 4);
+        }
+        int k_c0 = 0, k_tap = 0;
+        f32x4 ra[NR], rb[NR];
+        auto load_tiles = [&]() {
+            const unsigned sa = (unsigned)(k_c0 * 4), sb = (unsigned)((k_tap * p.Ca + k_c0) * 4);
+            if (doA) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) ra[i] = buf_load4(rx, a_cur[i], sa);
+            }
+            if (doB) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) rb[i] = buf_load4(rw, b_voff[i], sb);
+            }
+            k_c0 += KB;
+            if (k_c0 == p.Ca) {
+                k_c0 = 0; ++k_tap;
+                const unsigned off = (unsigned)(((k_tap / 3) * p.Wimg + (k_tap % 3)) * p.Ca * 4);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) a_cur[i] = (a_pad[i] && k_tap == 1) ? BUF_OOB : a_base[i] + off;
+            }
+        };
+        const bool has_act = p.slope != 1.0f;
+        auto store_tiles = [&](int buf) {
+            if (doA) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    if (has_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ra[i][e] = __builtin_amdgcn_fmed3f(ra[i][e], ra[i][e] * p.slope, p.pos_inf);
+                    }
+                    *reinterpret_cast<f32x4*>(&As[buf * A_SZ + (lrow + RPW * i) * LDK + aq]) = ra[i];
+                }
+            }
+            if (doB) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * B_SZ + (lrow + RPW * i) * LDK + aq]) = rb[i];
+            }
+        };
+        load_tiles();
+        store_tiles(0);
+        load_tiles();                 // step 1 (nk >= 2)
+        __syncthreads();              // barrier 0: buffer 0 holds step 0
+        for (int ks = 0; ks + 2 < nk; ks += 2) {
+            store_tiles(1);           // step ks + 1
+            load_tiles();             // step ks + 2
+            __syncthreads();
+            store_tiles(0);           // step ks + 2
+            load_tiles();             // step ks + 3 (exists: nk even)
+            __syncthreads();
+        }
+        store_tiles(1);               // step nk - 1
+        __syncthreads();
+        return;
+    }
+    // ---------------- MFMA waves
+    const int r = lane & 31, h = lane >> 5;
+    const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto step = [&](auto BUFC) {
+        constexpr int buf = decltype(BUFC)::value;
+        __syncthreads();
+        const float* Ab = As + buf * A_SZ;
+        const float* Bb = Bs + buf * B_SZ;
+        f32x4 a[KB / 8], b[KB / 8];
+#pragma unroll
+        for (int kk = 0; kk < KB / 8; ++kk) {
+            a[kk] = *reinterpret_cast<const f32x4*>(&Ab[(wm0 + r) * LDK + 8 * kk + 4 * h]);
+            b[kk] = *reinterpret_cast<const f32x4*>(&Bb[(wn0 + r) * LDK + 8 * kk + 4 * h]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KB / 8; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][e], b[kk][e], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int ks = 0; ks < nk; ks += 2) {
+        step(std::integral_constant<int, 0>());
+        step(std::integral_constant<int, 1>());
+    }
+    const int col = n0 + wn0 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < p.M && col < p.N) p.y[(long long)row * p.N + col] = acc[e];
+    }
+}
+
+template <int KB, int NL>
+static void run_ws(LabP p, const std::vector<double>& ref, int ref_rows) {
+    constexpr int BM = 64, BN = 64;
+    if ((p.T * p.Ca / KB) % 2 != 0 || p.Ca % KB != 0) return;
+    const dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), block(256 + 64 * NL);
+    CK(hipMemset(p.y, 0xFF, (size_t)p.M * p.N * 4));
+    hipLaunchKernelGGL((lab_ws_kernel<KB, NL>), grid, block, 0, 0, p);
+    CK(hipDeviceSynchronize());
+    std::vector<float> y((size_t)ref_rows * p.N);
+    CK(hipMemcpy(y.data(), p.y, y.size() * 4, hipMemcpyDeviceToHost));
+    double emax = 0, rmax = 0;
+    for (size_t i = 0; i < y.size(); ++i) { emax = fmax(emax, fabs((double)y[i] - ref[i])); rmax = fmax(rmax, fabs(ref[i])); }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 20;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((lab_ws_kernel<KB, NL>), grid, block, 0, 0, p);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((lab_ws_kernel<KB, NL>), grid, block, 0, 0, p);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    printf("%-44s %4dx%-3d KB%-2d  %8.4f ms %7.1f TF  err %.1e\n", NL == 1 ? "wave-specialised: 4 MFMA waves + 1 loader" : "wave-specialised: 4 MFMA waves + 2 loaders",
+           BM, BN, KB, ms, 2.0 * p.M * p.N * (double)p.T * p.Ca / ms / 1e9, emax / rmax);
+}
+
 // VAR 2: input patch resident in LDS.  The 3 x 3 taps of a tile of BM consecutive output rows read the BM + 2 * WIMG + 2 input rows
 // m0 .. m0 + BM + 2 * WIMG + 1: they are loaded ONCE per 16-channel chunk (K order: channel chunk outer, taps inner) and every tap's
 // A fragment is the same LDS image at a compile-time row offset (ds_read immediate) - 9x fewer activation loads, ds_writes,
@@ -692,6 +839,9 @@ int main(int argc, char** argv) {
                 run<64, 64, 1, 1, 32, 0, false>(p, "staged", ref, ref_rows);
                 if (s.N >= 128) run<64, 128, 1, 2, 16, 0, false>(p, "staged", ref, ref_rows);
                 run<128, 64, 2, 1, 16, 0, false>(p, "staged", ref, ref_rows);
+                run_ws<32, 1>(p, ref, ref_rows);
+                run_ws<32, 2>(p, ref, ref_rows);
+                run_ws<16, 1>(p, ref, ref_rows);
                 if (!p.oob_test) {
                     run_persist<32, false>(p, ref, ref_rows, 4);
                     run_persist<32, true>(p, ref, ref_rows, 4);
