@@ -379,6 +379,7 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cur = torch.cuda.current_stream()
         t0 = time.time()
+        c0 = os.times()
         ev0.record()
         marks = []
         for _ in range(args.steps):
@@ -386,8 +387,12 @@ def main():
             marks.append(cur.record_event(torch.cuda.Event(enable_timing=True)))   # no synchronisation: one event record per step
         _ops.join_lanes()   # the last discriminator step runs on its own stream: ev1 must come after it
         ev1.record()
+        t_enq = time.time() - t0     # the host has enqueued every step (it runs ahead of the device unless it is the bound)
         fence()
         dt = time.time() - t0
+        c1 = os.times()
+        host = {"enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+                "cpu_ms_per_step": round((c1.user - c0.user + c1.system - c0.system) / args.steps * 1e3, 3)}
         dev_ms = ev0.elapsed_time(ev1)
         ts = [ev0.elapsed_time(mk) for mk in marks]
         per_step = [b - a for a, b in zip([0.0] + ts[:-1], ts)]
@@ -406,7 +411,7 @@ def main():
             dist.all_gather(tall, torch.tensor([dt], device=device, dtype=torch.float64))
             ranks_dt = [float(t_.item()) for t_ in tall]
             dt = max(ranks_dt)
-        return dt, dev_ms, per_step, out, ar, ranks_dt
+        return dt, dev_ms, per_step, out, ar, ranks_dt, host
 
     if args.inner:   # a traffic pass: the steps only
         for _ in range(args.warmup + args.steps):
@@ -423,7 +428,7 @@ def main():
     exe_gf, algo_launch_gf, per_conv = summarize_flops(counts, _ops)
 
     matrix_path = "fp32 MFMA" if args.matrix_path == "fp32" else "fp16 operands / fp32 accumulate on eligible convolutions (v_mfma_f32_32x32x16_f16), fp32 MFMA elsewhere"
-    dt, dev_ms, per_step, out, allreduce_ms, ranks_dt = timed(matrix_path)
+    dt, dev_ms, per_step, out, allreduce_ms, ranks_dt, host_ms = timed(matrix_path)
     g_loss, d_loss = float(out[0][0]), float(out[1][0])
 
     if rank == 0:
@@ -448,6 +453,9 @@ def main():
             "allreduce_ms": allreduce_ms,
             "hw_queues": dict(G.hw_queues_state(), streams_check=streams_check),
             "cpu_affinity": pinned,
+            # host side of the timed region (rank 0): wall time until the last step was enqueued (< ms_per_step: the host ran ahead of the
+            # device) and CPU time of the process (all threads; includes the wait of the closing synchronisation)
+            "host": host_ms,
             "config": {"workload": "%s: %dx%dx%d synthetic episodes, m=%d n=%d k=%d, %d episodes/GPU, style_dim=512, "
                                    "G step + D step + 2 Adam updates per step, reg_param=%g" % (args.workload, u["S"], u["S"], u["C"], m, n, k, B, args.reg_param),
                        "global_batch": B * world, "parallelism": "dp%d (episodes sharded, 1 RCCL all-reduce per optimizer step)" % world,

@@ -42,10 +42,11 @@ def _backward(loss):
     """loss.backward() - on the fp16 matrix path of (loss * S), S = ops.loss_scale() (the optimizer step un-scales: FusedAdam.step
     (grad_scale=1 / S)), so that the gradients the fp16 convolution kernels round stay inside fp16's precise range."""
     s = ops.loss_scale()
-    if s != 1.0:
-        (loss * s).backward()
-    else:
-        loss.backward()
+    with ops.caller_thread_backward():     # (the nodes' Python on this thread: 15-25 % less host time per step, see ops)
+        if s != 1.0:
+            (loss * s).backward()
+        else:
+            loss.backward()
 
 
 def im_train_step(trainer, leaked_sample, si_sample, z=None):

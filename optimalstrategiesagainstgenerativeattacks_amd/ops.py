@@ -595,6 +595,20 @@ class ConvFn(Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
+# Backward's Python on the CALLING thread.  torch's autograd engine hands a backward pass to a per-device worker thread; every node
+# of this engine is a Python Function, and with the hand-off the host needs 31-37 ms to enqueue one training step where it needs 26-28 ms
+# when the calling thread runs the nodes itself (64x64x3, 16 episodes: the device needs 37 ms, so with the worker thread the host IS the
+# bound in part of the runs - 418-426 episodes/s instead of 429-431; at 1 / 4 episodes per step: 31 -> 42 / 132 -> 159 episodes/s;
+# profiles/r04_m_host_enqueue.txt).  Same graph, same kernels, same streams (the engine sets each node's forward stream either way).
+# GIM_MT_AUTOGRAD=1 restores torch's default.
+_CALLER_THREAD_BACKWARD = os.environ.get("GIM_MT_AUTOGRAD") is None
+
+
+def caller_thread_backward():
+    """Context for .backward() / autograd.grad() calls of the training step: autograd's nodes run on the calling thread."""
+    return torch.autograd.set_multithreading_enabled(not _CALLER_THREAD_BACKWARD)
+
+
 _ACT_STORAGE = os.environ.get("GIM_NO_ACT_STORAGE") is None   # A/B switch (host side)
 _ROWS_FORM = os.environ.get("GIM_NO_ROWS_FORM") is None   # A/B switch (host side): row-contiguous K for the image layers
 _MERGED_SUBPIXEL = os.environ.get("GIM_NO_MERGED_SUBPIXEL") is None   # A/B switch (host side): stacked parity classes for the 9x9 64->3 layer

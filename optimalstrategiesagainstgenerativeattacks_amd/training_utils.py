@@ -15,7 +15,7 @@ def compute_grad2(out, x_in):
     the authenticator's parameters (ops.input_grad_only documents how)."""
     from . import ops
     batch_size = x_in[0].size(0)
-    with ops.input_grad_only():
+    with ops.input_grad_only(), ops.caller_thread_backward():
         grad_out = torch.autograd.grad(outputs=out.sum(), inputs=x_in, create_graph=True, retain_graph=True, only_inputs=True)
     reg = None
     for g in grad_out:

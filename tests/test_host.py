@@ -468,3 +468,19 @@ def test_gaussian_loop_scatters_one_global_batch_over_the_ranks(monkeypatch):
             assert whole[j].shape[0] == 6
             both = torch.cat([runs[(2, 0)][it][j], runs[(2, 1)][it][j]])
             assert torch.equal(both, whole[j]), (it, j)
+
+
+def test_training_step_runs_autograd_nodes_on_the_calling_thread():
+    """ops.caller_thread_backward(): the context the training step's .backward() / autograd.grad() calls run under switches torch's
+    autograd engine to the calling thread (every node of the engine is a Python Function: the hand-off to the per-device worker thread
+    cost 15-25 % of the host's time per step, profiles/r04_m_host_enqueue.txt) and restores the previous mode on exit."""
+    import torch
+    from optimalstrategiesagainstgenerativeattacks_amd import ops
+    assert ops._CALLER_THREAD_BACKWARD      # the default (GIM_MT_AUTOGRAD unset)
+    before = torch.autograd.is_multithreading_enabled()
+    with ops.caller_thread_backward():
+        assert not torch.autograd.is_multithreading_enabled()
+        x = torch.ones(3, requires_grad=True)
+        (x * 2).sum().backward()
+        assert torch.equal(x.grad, torch.full((3,), 2.0))
+    assert torch.autograd.is_multithreading_enabled() == before
