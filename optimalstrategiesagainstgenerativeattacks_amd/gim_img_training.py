@@ -101,12 +101,14 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
     dstream = lane_stream(leaked_sample.device, 1)
 
     # generator: forward on the caller's stream
+    ops.mark_phase("step start")
     mod.impersonator.train()
     mod.impersonator_opt.zero_grad()
     loss, fake_sample, au_out = trainer.forward(mode='impersonator_forward', leaked_sample=leaked_sample,
                                                 si_sample=si_sample, **({} if z is None else {"z": z}))
     loss = loss.mean()
     fake_d = fake_sample.detach()
+    ops.mark_phase("G forward done")
     ops.stream_wait(dstream, cur)            # lane 1 forks here: everything up to the generator's forward is visible to it
     for t in (fake_d, real_sample, si_sample):
         t.record_stream(dstream)
@@ -115,23 +117,29 @@ def gim_step(trainer, leaked_sample, real_sample, si_sample, z=None, overlap=Non
     # FORWARD ahead of it - so that lane 1 starts ~8 ms of host time earlier - was measured 4 % SLOWER, 406 vs 423 episodes/s over
     # three alternating pairs on one box: lane 1's early kernels take the chip from the critical lane; profiles/r04_d_*)
     _backward(loss)
+    ops.mark_phase("G backward done")
     gbwd_done = cur.record_event()
     # generator's Adam right away: nothing on lane 1 reads the generator's weights, and with several GPUs its gradient
     # all-reduce (the larger bucket, 246 MB) then runs under the discriminator step instead of after it
     mod.impersonator_opt.step(grad_scale=1.0 / ops.loss_scale())
+    ops.mark_phase("G update done")
     im = (loss.detach(), fake_d, au_out.detach())
 
     # discriminator step on lane 1
     with torch.cuda.stream(dstream), ops.lane(1):
+        ops.mark_phase("D start")
         mod.authenticator.train()
         mod.authenticator_opt.zero_grad()
         (dloss, loss_on_real, loss_on_fake, reg, out_on_real, out_on_fake, pred_on_real, pred_on_fake,
          fake_out) = trainer.forward(mode='authenticator_forward', fake_sample=fake_d, real_sample=real_sample,
                                      si_sample=si_sample)
         dloss = dloss.mean()
+        ops.mark_phase("D forward done")
         _backward(dloss)
+        ops.mark_phase("D backward done")
         dstream.wait_event(gbwd_done)   # the generator's backward reads the weights this update overwrites
         mod.authenticator_opt.step(grad_scale=1.0 / ops.loss_scale())
+        ops.mark_phase("D update done")
         au = (dloss.detach(), loss_on_real.detach().mean(), loss_on_fake.detach().mean(), reg.detach().mean(),
               out_on_real.detach().mean(), out_on_fake.detach().mean(),
               pred_on_real.detach(), pred_on_fake.detach(), fake_out.detach())

@@ -49,6 +49,30 @@ def _second_order():
 # the multiply-adds its kernel EXECUTES (the pool / sub-pixel folds run (K+1)^2 taps at a quarter of the pixels, not the
 # K^2 full-resolution taps of the unfused reference op) to a Counter keyed by (kind, shape).  Off (None) otherwise.
 _FLOPS = None
+_PHASES = None     # phase_timeline(): a list that gim_step's phase marks are appended to
+
+
+class phase_timeline:
+    """with ops.phase_timeline() as marks: gim_step(...)  ->  marks = [(name, event), ...]: one timing event per phase boundary of the
+    overlapped training step, recorded on the stream the phase runs on (lane 0 = the caller's stream, lane 1 = the discriminator's).
+    bench.py --phases turns them into the step's timeline; nothing is recorded outside the context."""
+
+    def __enter__(self):
+        global _PHASES
+        self.prev = _PHASES
+        _PHASES = []
+        return _PHASES
+
+    def __exit__(self, *a):
+        global _PHASES
+        _PHASES = self.prev
+
+
+def mark_phase(name):
+    if _PHASES is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        _PHASES.append((name, ev))
 
 
 class count_flops:
