@@ -41,9 +41,29 @@ def main():
         lib.gim_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), Cout, Cin, KF, st)
         dgrad = lambda: lib.gim_conv2d_dgrad_t(y.data_ptr(), wt.data_ptr(), None, None, dx.data_ptr(), sh, st)   # noqa: E731
         plan_kind = 2 if kind == "dgrad" else plan_kind
-    fn = {"fwd": lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st),
-          "dgrad": dgrad,
-          "wgrad": lambda: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh, st)}[kind]
+    fwd = lambda: lib.gim_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), sh, st)   # noqa: E731
+    wgrad = lambda: lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), acc.data_ptr(), None, sh, st)   # noqa: E731
+    plain = not (ups or pool or fold)
+    J = ops._xfold_factor(Cin, H) if (K >= 3 and plain and Cout % 16 == 0 and ops._NARROW_XFOLD) else 0
+    if J:   # as ops._conv_dgrad: the x-folded gradient w.r.t. images
+        wx = torch.empty(J * Cin * K * (K + J - 1) * Cout, device=dev)
+        lib.gim_conv2d_xfold_weights(w.data_ptr(), wx.data_ptr(), Cout, Cin, K, J, st)
+        dgrad = lambda: lib.gim_conv2d_dgrad_xfold(y.data_ptr(), wx.data_ptr(), None, None, dx.data_ptr(), sh, J, st)   # noqa: E731
+    if ops._ROWS_FORM and K >= 3 and Cin <= 8 and K * Cin <= 64 and Cout >= 16 and Cout % 4 == 0 and plain and tile == 0:
+        # as ops.ConvFn: row-contiguous K on a zero-padded, activated copy of the image (the copy is part of the forward)
+        pad, CaP = (K - 1) // 2, (K * Cin + 15) & ~15
+        xp = torch.empty(N, H + 2 * pad, H + 2 * pad, Cin, device=dev)
+        wr = torch.empty(Cout * K * CaP, device=dev)
+        lib.gim_conv2d_pack_rows_weights(w.data_ptr(), wr.data_ptr(), Cout, Cin, K, st)
+        shr = _lib.GimConvShape(N, H, H, Cin, Cout, K, 0, 1.0, 0, 0, 0, 0, 1)
+        accr = torch.zeros(Cout * K * CaP, device=dev)
+
+        def fwd():
+            lib.gim_pad_image(x.data_ptr(), xp.data_ptr(), N, H, H, Cin, pad, slope, st)
+            lib.gim_conv2d_fwd_rows(xp.data_ptr(), wr.data_ptr(), None, None, None, y.data_ptr(), shr, st)
+        lib.gim_pad_image(x.data_ptr(), xp.data_ptr(), N, H, H, Cin, pad, slope, st)
+        wgrad = lambda: lib.gim_conv2d_wgrad_rows_acc(y.data_ptr(), xp.data_ptr(), accr.data_ptr(), None, shr, st)   # noqa: E731
+    fn = {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad}[kind]
     plan = (ctypes.c_int32 * 8)()
     lib.gim_conv_launch_plan(sh, plan_kind, ctypes.cast(plan, ctypes.c_void_p))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

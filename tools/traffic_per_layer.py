@@ -8,13 +8,21 @@ import sys
 root = sys.argv[1]
 
 
+CONV = ("void conv_igemm_kernel", "void conv_igemm_patch", "void conv_wgrad_kernel", "void conv_wgrad_row_kernel")
+EXTRA = ("pad_image_kernel",)      # the image copy of the row-contiguous form: part of every forward launch
+
+
 def mean_kib(d):
-    vals = []
+    """Counter value per conv launch: the conv kernel's own, plus the per-launch helper kernels of its launch form."""
+    total, n = 0.0, 0
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith(("void conv_igemm_kernel", "void conv_igemm_patch", "void conv_wgrad_kernel", "void conv_wgrad_row_kernel")):
-                vals.append(float(r["Counter_Value"]))
-    return sum(vals) / len(vals) if vals else float("nan")
+            if r["Kernel_Name"].startswith(CONV):
+                total += float(r["Counter_Value"])
+                n += 1
+            elif r["Kernel_Name"].startswith(EXTRA):
+                total += float(r["Counter_Value"])
+    return total / n if n else float("nan")
 
 
 print("%-6s %-28s %9s %9s %9s | %9s %7s   (MB per launch; operands = x + w + y touched once)" % ("kind", "N,H,Cin,Cout,K,pool", "fetch x2", "write", "total", "operands", "ratio"))
