@@ -207,7 +207,10 @@ int gim_depth_to_space2(const float* y4, const float* bias, float* y, int N, int
  *   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
  *   out[8] = {1 if a row of the compiled-in per-shape launch table matched, tile rows, tile columns, split-K factor
  *             (wgrad: pixel slices), grid x, y, z, loop form: 0 = tap-major K loop, 1 = patch-resident (plain 3x3 layers: the input
- *             patch of a tile stays in LDS for all nine taps; tune_tile + 20000 selects it explicitly)}.
+ *             patch of a tile stays in LDS for all nine taps; tune_tile + 20000 selects it explicitly), 2 = fp16 operands, 3 = direct
+ *             kernel of the 3 -> 3 / 1 -> 1 image layers}; out[7] bits 8 and up: the share of the launch's K steps that is SKIPPED,
+ *             in 1/1000 - the tap-major loop on maps of <= 16 pixels and >= 32 images orders its GEMM rows by pixel position and skips,
+ *             per tile, the taps that fall into the zero padding for all of its rows (31 % of a 3x3 convolution on a 4x4 map).
  * A batch beyond the 32-bit buffer-offset range (the entry points then halve it) reports the plan of its last half. */
 int gim_conv_launch_plan(const gim_conv_shape* shape, int kind, int32_t* out);
 

@@ -29,6 +29,8 @@
 #include "common.h"
 #include <type_traits>
 
+#define PM_MAX_PIXELS 16    // position-major rows (Geo.pm) for logical maps up to 4 x 4 (larger maps: measured slower, profiles/r04_p_*) ...
+#define PM_MIN_IMAGES 32    // ... of at least this many images (a 64-row tile then holds <= 3 pixel positions)
 #define BK 16  // wgrad pixel step; also the K granularity the fast paths require (channels % 16 == 0)
 
 struct Geo {
@@ -44,10 +46,34 @@ struct Geo {
     int wa_base, wa_step, wb_base, wb_step;  // weight tap (a, b) = (wa_base + wa_step * ta, wb_base + wb_step * tb)
     int os, py, px;           // output pixel = (oy * os + py, ox * os + px) in an (H*os) x (W*os) image
     int pc, pc_kind, pc_K;    // PC mode: blockIdx.z & 3 = class; class parameters derived in the kernel
+    int pm;                   // POSITION-MAJOR rows (maps of <= 16 logical pixels, conv_igemm_kernel fast path): GEMM row m = slot * N + image,
+                              // pixel = nibble `slot` of pm_perm - the rows of a tile share (at most a few) pixel positions, so the taps that
+                              // fall into the zero padding for ALL of them are skipped: 31 % of the MACs of a 3x3 convolution on a 4x4 map,
+                              // 23 % of the pool fold of an 8x8 map, 75 % of the sub-pixel classes of a 1x1 -> 2x2 map
+    unsigned long long pm_perm;       // slot -> pixel, 4 bits each: pixels with the SAME set of valid taps sit next to each other (a tile that
+    unsigned long long pm_perm_cls[4];  // straddles two slots then skips what both skip); per parity class in PC mode
 };
 
+__host__ __device__ __forceinline__ int pm_pixel(unsigned long long perm, int slot) { return (int)((perm >> (4 * slot)) & 15ull); }
+
+
+// GEMM row -> (image, logical pixel)
+__device__ __forceinline__ void geo_row(const Geo& g, int m, int& n, int& oy, int& ox) {
+    if (g.pm) {
+        const int slot = m / g.N;
+        n = m - slot * g.N;
+        const int pix = pm_pixel(g.pm_perm, slot);
+        oy = pix >> g.logW;
+        ox = pix & (g.W - 1);
+    } else {
+        n = m >> (g.logH + g.logW);
+        oy = (m >> g.logW) & (g.H - 1);
+        ox = m & (g.W - 1);
+    }
+}
+
 // class-dependent part of a PC geometry (uniform per workgroup)
-__device__ __forceinline__ void geo_select_class(Geo& g, int cls) {
+__host__ __device__ __forceinline__ void geo_select_class(Geo& g, int cls) {
     const int py = cls >> 1, px = cls & 1;
     const int K = g.pc_K, pd = (K - 1) / 2;
     g.py = py;
@@ -149,6 +175,8 @@ struct EpiCtx {
     float scale, mask_slope, post_slope;
     float res_scale;   // MODE 4: factor of the half-resolution residual (0.25: the average pool's backward)
     int M, Cb, logH, logW, Hm1, Wm1, os, py, px, Ho, Wo;
+    int pmN;           // > 0: position-major rows (Geo.pm), m = slot * pmN + image, pixel = nibble `slot` of pm_perm
+    unsigned long long pm_perm;
     bool atom, remap;
 };
 
@@ -171,11 +199,11 @@ __device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE],
         unsigned off[CH], roff[(MODE == 2 || MODE == 4) ? CH : 1];
         // rows come in groups of 4 consecutive m (mbase % 4 == 0): one full address computation per group where a group stays in
         // one image row (W >= 4), plain arithmetic otherwise; out-of-range lanes get the high bit (>= num_records: dropped)
-        if (!c.remap && MODE != 2 && MODE != 4) {
+        if (!c.remap && !c.pmN && MODE != 2 && MODE != 4) {
             const unsigned base = (unsigned)((mbase * c.Cb + co) * 4);
 #pragma unroll
             for (int q = 0; q < CH; ++q) off[q] = base + (unsigned)(((e0 + q) & 3) + 8 * ((e0 + q) >> 2)) * rowb;
-        } else if (c.Wm1 >= 3) {
+        } else if (c.Wm1 >= 3 && !c.pmN) {
 #pragma unroll
             for (int g4 = 0; g4 < CH; g4 += 4) {
                 unsigned o, ro = 0;
@@ -185,6 +213,20 @@ __device__ __forceinline__ void epi_block(const EpiCtx& c, const float (&a)[NE],
                     off[g4 + k] = o + (unsigned)(k * c.os) * rowb;
                     if constexpr (MODE == 2 || MODE == 4) roff[g4 + k] = ro + (unsigned)(((c.px + k * c.os) >> 1) - (c.px >> 1)) * rowb;
                 }
+            }
+        } else if (c.pmN) {
+            // position-major rows (m = pixel * N + image, N >= 32): ONE division for the block's first row; the other rows of the chunk
+            // are < 32 rows further on, i.e. in the same or the next pixel position
+            const int slot0 = mbase / c.pmN, n0 = mbase - slot0 * c.pmN;
+            const int pixa = pm_pixel(c.pm_perm, slot0), pixb = pm_pixel(c.pm_perm, (slot0 + 1) & 15);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int d = ((e0 + q) & 3) + 8 * ((e0 + q) >> 2);
+                const bool wrap = n0 + d >= c.pmN;
+                const int n = wrap ? n0 + d - c.pmN : n0 + d, pix = wrap ? pixb : pixa;
+                const int oy = ((pix >> c.logW) & c.Hm1) * c.os + c.py, ox = (pix & c.Wm1) * c.os + c.px;
+                off[q] = (unsigned)((((n * c.Ho + oy) * c.Wo + ox) * c.Cb + co) * 4);
+                if constexpr (MODE == 2 || MODE == 4) roff[q] = (unsigned)((((n * (c.Ho >> 1) + (oy >> 1)) * (c.Wo >> 1) + (ox >> 1)) * c.Cb + co) * 4);
             }
         } else {
 #pragma unroll
@@ -268,6 +310,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
     int kslice = blockIdx.z;
     if (g.pc) {
         geo_select_class(g, blockIdx.z & 3);
+        g.pm_perm = p.g.pm_perm_cls[blockIdx.z & 3];   // (indexed in the kernel-argument segment: a dynamic index into the local copy would put it in scratch)
         kslice = blockIdx.z >> 2;
     }
     const int t = threadIdx.x;
@@ -316,9 +359,10 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             const int m = min(m0 + arow + RP * i, p.M - 1);
-            const int n = m >> (g.logH + g.logW);
-            a_oy[i] = ((m >> g.logW) & (g.H - 1)) * g.s_in + g.off_y;
-            a_ox[i] = (m & (g.W - 1)) * g.s_in_x + g.off_x;
+            int n, oy, ox;
+            geo_row(g, m, n, oy, ox);
+            a_oy[i] = oy * g.s_in + g.off_y;
+            a_ox[i] = ox * g.s_in_x + g.off_x;
             a_base[i] = (unsigned)((n * g.Hin * g.Win * p.pix + aq) * 4);
             a_cur[i] = BUF_OOB;
         }
@@ -354,8 +398,41 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
     float rb1[B_PER];
     f32x4 rb4[B_PER4];
 
+    // position-major rows: the taps that reach at least one of the tile's pixel positions (block-uniform; scalar code)
+    unsigned tapmask = 0xFFFFFFFFu;
+    if constexpr (!GEN) {
+        if (g.pm) {
+            tapmask = 0;
+            const int slot0 = m0 / g.N, slot1 = min(m0 + BM - 1, p.M - 1) / g.N;
+            for (int slot = slot0; slot <= slot1; ++slot) {
+                const int pix = pm_pixel(g.pm_perm, slot);
+                const int oy = (pix >> g.logW) * g.s_in + g.off_y, ox = (pix & (g.W - 1)) * g.s_in_x + g.off_x;
+                for (int ta = 0; ta < g.Th; ++ta)
+                    for (int tb = 0; tb < g.Tw; ++tb)
+                        if ((unsigned)(oy + ta) < (unsigned)He && (unsigned)(ox + tb) < (unsigned)We) tapmask |= 1u << (ta * g.Tw + tb);
+            }
+        }
+    }
     // wave-uniform K position, advanced incrementally by load_tiles (fast path)
     int k_c0 = 0, k_ta = 0, k_tb = 0;
+    // position-major rows: K steps are counted over the VALID taps only; tap index of the v-th valid tap / of the next one
+    auto pm_seek = [&](int vstep) {
+        const int cps = p.Ca / KB;
+        int q = vstep / cps, tap = 0;
+        k_c0 = (vstep - q * cps) * KB;
+        for (;; ++tap)
+            if ((tapmask >> tap) & 1u) { if (q == 0) break; --q; }
+        k_ta = tap / g.Tw;
+        k_tb = tap - k_ta * g.Tw;
+    };
+    auto pm_next_tap = [&]() {
+        int tap = k_ta * g.Tw + k_tb;
+        const int T = g.Th * g.Tw;
+        do { ++tap; } while (tap < T && !((tapmask >> tap) & 1u));
+        if (tap >= T) tap = T - 1;     // behind the last valid tap: the step that would use it is never loaded for the MFMAs
+        k_ta = tap / g.Tw;
+        k_tb = tap - k_ta * g.Tw;
+    };
     // K order: tap-major (all channel chunks of a tap, then the next tap).  (A channel-group-major order halved the L2 misses of
     // the dominant layer in round 1 and was not faster: profiles/r01_k_conv_k_order.txt.)
     auto seek = [&](int k0) {
@@ -398,7 +475,8 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
             k_c0 += KB;
             if (k_c0 == p.Ca) {
                 k_c0 = 0;
-                if (++k_tb == g.Tw) { k_tb = 0; ++k_ta; }
+                if (g.pm) pm_next_tap();
+                else if (++k_tb == g.Tw) { k_tb = 0; ++k_ta; }
                 set_tap(k_ta, k_tb);
             }
         } else {
@@ -526,9 +604,24 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
     for (int i = 0; i < NB16; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk_all = (p.Ktot + KB - 1) / KB;
-    const int ks0 = kslice * p.kper;
-    const int nk = min(nk_all, ks0 + p.kper);
-    if constexpr (!GEN) seek(ks0 * KB);
+    int ks0 = kslice * p.kper;
+    int nk = min(nk_all, ks0 + p.kper);
+    bool pm_started = false;
+    if constexpr (!GEN) {
+        if (g.pm) {   // the slices divide the VALID steps of this tile
+            const int nv = __builtin_popcount(tapmask) * (p.Ca / KB);
+            const int per = (nv + p.ksplit - 1) / p.ksplit;
+            ks0 = kslice * per;
+            nk = min(nv, ks0 + per);
+            if (ks0 >= nk) {
+                if (kslice != 0) return;   // (block-uniform) nothing left for this slice; slice 0 always has the centre tap
+            }
+            pm_seek(ks0);
+            set_tap(k_ta, k_tb);
+            pm_started = true;
+        }
+    }
+    if constexpr (!GEN) { if (!pm_started) seek(ks0 * KB); }
     load_tiles(ks0 * KB);
     store_tiles(0);
     __syncthreads();
@@ -605,6 +698,7 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
 
     // ---- epilogue: out_scale/sigma, bias, residual, activation mask; logical pixel -> stored pixel ----
     EpiCtx ec;
+    ec.pmN = 0;
     ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
     ec.mask_slope = p.mask_slope;
     ec.post_slope = p.post_slope;
@@ -616,6 +710,8 @@ __global__ __launch_bounds__(256, igemm_lds_bytes(BM, BN, KB, BMODE) <= 40960 ? 
     ec.M = p.M; ec.Cb = p.Cb;
     ec.logH = g.logH; ec.logW = g.logW; ec.Hm1 = g.H - 1; ec.Wm1 = g.W - 1; ec.os = g.os; ec.py = g.py; ec.px = g.px;
     ec.Ho = g.H * g.os; ec.Wo = g.W * g.os;
+    ec.pmN = g.pm ? g.N : 0;
+    ec.pm_perm = g.pm_perm;
     // y (and the mask, which has y's shape) in bytes: the host guarantees < 2 GiB per launch
     const unsigned ybytes = (unsigned)g.N * (unsigned)ec.Ho * (unsigned)ec.Wo * (unsigned)p.Cb * 4u;
     ec.ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
@@ -862,6 +958,7 @@ __global__ __launch_bounds__(256, TM * TN <= 2 ? 3 : 2) void conv_igemm_patch_ke
 
     // ---- epilogue (as conv_igemm_kernel) ----
     EpiCtx ec;
+    ec.pmN = 0;
     ec.scale = p.out_scale * (p.sigma ? 1.0f / p.sigma[0] : 1.0f);
     ec.mask_slope = p.mask_slope;
     ec.post_slope = p.post_slope;
@@ -1590,6 +1687,64 @@ static const TuneEntry* tune_lookup(int kind, int M, int Ca, int Cb, int Ktot, i
     return nullptr;
 }
 
+// Position-major rows (Geo.pm): the slot -> pixel order of a launch (of each parity class in PC mode): pixels sorted by their set of
+// valid taps, so that neighbouring slots - the ones a tile straddles - skip the same taps
+static unsigned long long pm_perm_of(const Geo& g) {
+    const int P = g.H * g.W, He = g.Hin << g.ups, We = g.Win << g.ups;
+    unsigned mask[16];
+    int order[16];
+    for (int pix = 0; pix < P; ++pix) {
+        const int oy = (pix >> g.logW) * g.s_in + g.off_y, ox = (pix & (g.W - 1)) * g.s_in_x + g.off_x;
+        unsigned mk = 0;
+        for (int ta = 0; ta < g.Th; ++ta)
+            for (int tb = 0; tb < g.Tw; ++tb)
+                if ((unsigned)(oy + ta) < (unsigned)He && (unsigned)(ox + tb) < (unsigned)We) mk |= 1u << (ta * g.Tw + tb);
+        mask[pix] = mk;
+        order[pix] = pix;
+    }
+    for (int i = 1; i < P; ++i)   // stable insertion sort by mask
+        for (int j = i; j > 0 && mask[order[j - 1]] > mask[order[j]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    unsigned long long perm = 0;
+    for (int sl = 0; sl < P; ++sl) perm |= (unsigned long long)order[sl] << (4 * sl);
+    return perm;
+}
+static void pm_make_perms(Geo& g) {
+    if (g.pc) {
+        for (int cls = 0; cls < 4; ++cls) {
+            Geo c = g;
+            geo_select_class(c, cls);
+            g.pm_perm_cls[cls] = pm_perm_of(c);
+        }
+    } else {
+        g.pm_perm = pm_perm_of(g);
+    }
+}
+
+// what the kernel's tap mask leaves of a launch's K steps, in 1/1000 (1000 without position-major rows): for gim_conv_launch_plan
+static int pm_valid_permille(const Geo& g0, int M, int BM) {
+    if (!g0.pm) return 1000;
+    long long valid = 0, total = 0;
+    for (int cls = 0; cls < (g0.pc ? 4 : 1); ++cls) {
+        Geo g = g0;
+        if (g.pc) { geo_select_class(g, cls); g.pm_perm = g0.pm_perm_cls[cls]; }
+        const int He = g.Hin << g.ups, We = g.Win << g.ups;
+        for (int m0 = 0; m0 < M; m0 += BM) {
+            unsigned mask = 0;
+            const int last = m0 + BM - 1 < M - 1 ? m0 + BM - 1 : M - 1;
+            for (int slot = m0 / g.N; slot <= last / g.N; ++slot) {
+                const int pix = pm_pixel(g.pm_perm, slot);
+                const int oy = (pix >> g.logW) * g.s_in + g.off_y, ox = (pix & (g.W - 1)) * g.s_in_x + g.off_x;
+                for (int ta = 0; ta < g.Th; ++ta)
+                    for (int tb = 0; tb < g.Tw; ++tb)
+                        if ((unsigned)(oy + ta) < (unsigned)He && (unsigned)(ox + tb) < (unsigned)We) mask |= 1u << (ta * g.Tw + tb);
+            }
+            valid += __builtin_popcount(mask);
+            total += g.Th * g.Tw;
+        }
+    }
+    return (int)((valid * 1000 + total / 2) / total);
+}
+
 // split-K factor: explicit (shape->tune_ksplit), else the table's, else enough workgroups to give every CU several, never
 // fewer than 8 K-steps per split
 static int plan_ksplit(long long wgs, int nk, int tile_area, int want_ks) {
@@ -1613,11 +1768,20 @@ static void launch_cfg_kb(ConvP p, size_t y_elems, hipStream_t st, bool table_hi
     const int gx = (p.M + BM - 1) / BM, gy = (p.Cb + BN - 1) / BN;
     const int ncls = p.g.pc ? 4 : 1;
     const int nk = (p.Ktot + KB - 1) / KB;
+#ifndef GIM_NO_PM   // (a second build of the library for same-box A/B runs)
+    // small maps: position-major rows, padding taps skipped (Geo.pm) - a tile of BM rows then holds BM / N pixel positions
+    if constexpr (GEN == 0) {
+        const int taps = p.g.Th * p.g.Tw;
+        p.g.pm = (taps > 1 && taps <= 32 && p.g.H * p.g.W <= PM_MAX_PIXELS && p.g.N >= PM_MIN_IMAGES && p.pix == p.Ca && p.Ca % KB == 0) ? 1 : 0;
+        if (p.g.pm) pm_make_perms(p.g);
+    }
+#endif
     p.ksplit = plan_ksplit((long long)gx * gy * ncls, nk, BM * BN, p.tune_ks);
     p.kper = (nk + p.ksplit - 1) / p.ksplit;
     p.ksplit = (nk + p.kper - 1) / p.kper;
     if (t_plan_out) {
-        const int32_t v[8] = {table_hit ? 1 : 0, BM, BN, p.ksplit, gx, gy, p.ksplit * ncls, 0};
+        // out[7] bits 8..: the share of the launch's K steps that is SKIPPED, in 1/1000 (position-major rows skip padding taps; else 0)
+        const int32_t v[8] = {table_hit ? 1 : 0, BM, BN, p.ksplit, gx, gy, p.ksplit * ncls, (1000 - pm_valid_permille(p.g, p.M, BM)) << 8};
         for (int i = 0; i < 8; ++i) t_plan_out[i] = v[i];
         return;
     }

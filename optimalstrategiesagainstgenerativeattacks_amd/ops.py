@@ -105,12 +105,20 @@ def conv_algorithmic_flops(N, H, W, Cin, Cout, KH, *_):
     return 2.0 * N * H * W * Cin * Cout * KH * KH
 
 
-def _note_conv(kind, cfg):
+def _note_conv(kind, cfg, sh=None, plan_kind=None):
+    """Count one conv launch (ops.count_flops).  sh / plan_kind (the launch's gim_conv_shape and its gim_conv_launch_plan kind): the
+    library is asked which share of the launch's K steps its kernel skips (position-major rows on small maps skip padding taps,
+    include/gim_hip.h gim_conv_launch_plan out[7]) - skipped multiply-adds are not executed FLOPs."""
     N, H, W, Cin, Cout, KH, ups, pre_slope, has_bias, has_res, pool, fold, res_ups = cfg
     key = (kind, (N, H, W, Cin, Cout, KH, int(ups), int(bool(pool)), int(fold)))
     ent = _FLOPS.get(key)
     if ent is None:
-        _FLOPS[key] = [1, conv_executed_flops(*key[1])]
+        share = 1.0
+        if sh is not None:
+            out = (ctypes.c_int32 * 8)()
+            check(_lib.load().gim_conv_launch_plan(ctypes.byref(sh), plan_kind, ctypes.cast(out, ctypes.c_void_p)), "conv_launch_plan")
+            share = 1.0 - (out[7] >> 8) / 1000.0
+        _FLOPS[key] = [1, conv_executed_flops(*key[1]) * share]
     else:
         ent[0] += 1
 
@@ -569,7 +577,7 @@ class ConvFn(Function):
         ctx.guard = guard
         ctx.x_act = bool(x_act)
         if _FLOPS is not None:
-            _note_conv("fwd", ctx.cfg)
+            _note_conv("fwd", ctx.cfg, sh, 0)
         return y
 
     @staticmethod
@@ -705,7 +713,7 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None, res_half=None):
             and not (sh.prec == 1 and Cout % 32 == 0 and Cin >= 32)
         if plain:
             if _FLOPS is not None:
-                _note_conv("dgrad", cfg)
+                _note_conv("dgrad", cfg, sh, 1)
             key = (N, H, W, Cin, Cout, KH, ups, 0, 0)
             dx = _conv_out(sh, 1, key, tuple(x.shape), x.device)
             check(lib.gim_conv2d_dgrad_res(_p(dy), _p(wp), _p(sigma), _p(x), _p(_req(res_half, "res_half")), 0.25, _p(dx), sh, st), "conv2d_dgrad_res")
@@ -715,7 +723,7 @@ def _conv_dgrad(lib, dy, x, wp, wf, sigma, sh, cfg, st, w=None, res_half=None):
         check(lib.gim_add_avgpool2_bwd(_p(g), _p(_req(res_half, "res_half")), _p(out), N, H, W, Cin, st), "add_avgpool2_bwd")
         return out
     if _FLOPS is not None:
-        _note_conv("dgrad", cfg)
+        _note_conv("dgrad", cfg, sh, 1)
     mask = x if pre_slope != 1.0 else None
     key = (N, H, W, Cin, Cout, KH, ups, 1 if pool else 0, fold)
     wk = wf if fold else wp
@@ -856,7 +864,7 @@ class ConvDgradFn(Function):
             g_dy = torch.empty_like(dy)
             check(lib.gim_conv2d_fwd(_p(gm), _p(wf if fold else wp), None, _p(sigma), None, _p(g_dy), sh, st), "conv2d_fwd")
             if _FLOPS is not None:
-                _note_conv("fwd", lin)
+                _note_conv("fwd", lin, sh, 0)
         if ctx.needs_input_grad[1]:
             g_w, _ = _conv_wgrad(lib, dy, gm, w, wp, None, sigma, u_s, v_s, sh, lin, False, st)
         return g_dy, g_w, None, None, None, None, None, None

@@ -50,6 +50,13 @@ CONV_CASES = [
     (1, 16, 32, 3, 128, 0, 0.2, True, True),       # patch-resident loop, 128-wide map: a 64-pixel tile is half an image row
     (5, 32, 48, 3, 8, 0, 0.2, False, True),        # patch-resident loop, 8x8 map: one tile = one image, ragged output channels
     (3, 48, 96, 3, 4, 0, 0.2, True, True),         # 4x4 map: below the patch kernel's 64 pixels, tap-major loop
+    # >= 32 images on maps of <= 256 pixels: position-major rows, padding taps skipped (csrc/conv_igemm.hip Geo.pm)
+    (40, 32, 48, 3, 4, 0, 0.2, True, True),        # 4x4 map, 64-row tiles straddle pixel positions (40 images), ragged output channels
+    (35, 16, 32, 3, 8, 0, 1.0, False, True),       # 35 images: positions do not start on 4-row groups
+    (64, 32, 64, 3, 2, 0, 0.2, True, False),       # 2x2 map: one tile = one position, 4 of 9 taps valid
+    (33, 32, 64, 3, 8, 1, 0.2, False, True),       # sub-pixel classes on a 4x4 -> 8x8 map
+    (48, 32, 32, 3, 16, 1, 0.2, True, True),       # sub-pixel, residual at full resolution, 8x8 -> 16x16
+    (32, 64, 128, 3, 16, 0, 0.2, True, True),      # 16x16 map (256 pixels, the largest position-major map); forward: patch-resident loop
 ]
 
 POOL_CASES = [
@@ -64,6 +71,11 @@ POOL_CASES = [
     (3, 32, 64, 1, 16, 1.0, True),      # 1x1 + pool = 2x2 stride 2 (the skip convs of ResBlockDown)
     (2, 3, 64, 1, 16, 1.0, False),      # ... of the first block (image channels: generic-K)
     (5, 128, 256, 1, 2, 1.0, False),    # 2x2 -> 1x1
+    # position-major rows (>= 32 images, small maps): the stride-2 fold and its parity-class dgrad skip their padding taps
+    (40, 32, 32, 3, 8, 0.2, True),      # 8x8 -> 4x4, tiles straddle positions
+    (36, 16, 48, 3, 4, 0.2, False),     # 4x4 -> 2x2
+    (32, 32, 64, 3, 16, 1.0, True),     # 16x16 -> 8x8
+    (34, 16, 16, 9, 8, 0.2, False),     # 9x9 + pool: 100 taps - more than the tap mask holds, stays image-major
 ]
 
 

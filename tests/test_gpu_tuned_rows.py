@@ -76,7 +76,7 @@ def test_every_table_row_is_reachable_from_its_shape():
             continue   # wgrad rows carry a workgroup target, not a tile
         if tile:   # tile code + 20000: the patch-resident kernel (plain 3x3 layers), reported in plan[7]
             assert tuple(plan[1:3]) == tiles[tile % 20000], (kind, name, cfg, plan, tile)
-            assert plan[7] == (1 if tile >= 20000 else 0), (kind, name, cfg, plan, tile)
+            assert plan[7] & 255 == (1 if tile >= 20000 else 0), (kind, name, cfg, plan, tile)   # (bits 8..: skipped share of the K steps)
         # the split-K factor is the row's, capped by the number of K steps and rounded to whole steps per slice
         assert 1 <= plan[3] <= max(ks, 1), (kind, name, cfg, plan, ks)
 

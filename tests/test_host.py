@@ -364,7 +364,15 @@ def test_deterministic_switch_forces_one_k_slice_and_slab_weight_gradients():
         assert ops.set_deterministic(True) is False and ops.deterministic()
         sh = ops._shape(*args)
         assert sh.tune_ksplit == 1 and plan(sh, 0)[3] == 1 and plan(sh, 1)[3] == 1
-        assert plan(sh, 0)[7] == 0      # and the tap-major loop (one K order whatever the batch): not the patch-resident kernel
+        assert plan(sh, 0)[7] & 255 == 0      # and the tap-major loop (one K order whatever the batch): not the patch-resident kernel
+        # ... on position-major rows (a map of <= 16 pixels, >= 32 images): plan[7] >> 8 = the skipped share of its K steps in 1/1000.
+        # 80 images on a 4 x 4 map in 64-row tiles: between nothing and the 30.6 % of (pixel, tap) pairs that fall into the padding
+        assert 150 <= plan(sh, 0)[7] >> 8 <= 306 and 150 <= plan(sh, 1)[7] >> 8 <= 306, (plan(sh, 0), plan(sh, 1))
+        one = ops._shape(64, 2, 2, 512, 512, 3, 0, 0.2)   # 64 images, 2 x 2 map: one tile = one pixel, 4 of its 9 taps are inside the map
+        assert plan(one, 0)[7] >> 8 == 556 and plan(one, 1)[7] >> 8 == 556, (plan(one, 0), plan(one, 1))
+        few = ops._shape(16, 4, 4, 512, 512, 3, 0, 0.2)   # 16 images: image-major rows, nothing skipped
+        big = ops._shape(80, 16, 16, 128, 128, 3, 0, 0.2)
+        assert plan(few, 0)[7] >> 8 == 0 and plan(big, 0)[7] >> 8 == 0
         assert lib.gim_conv2d_wgrad_slabs(ctypes.byref(sh)) >= 1
     finally:
         ops.set_deterministic(prev)

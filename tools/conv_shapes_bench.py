@@ -5,6 +5,7 @@ the forward, dgrad and wgrad kernels of each distinct shape through the C ABI wi
 """
 import argparse
 import collections
+import ctypes
 import os
 import sys
 
@@ -124,21 +125,28 @@ def main():
             else:
                 lib.gim_conv2d_wgrad_acc(y.data_ptr(), x.data_ptr(), slabs.data_ptr(), None, sh, st)
         t_w = time_ms(wg) if n_dw else 0.0
+        # share of the K steps the forward / dgrad kernel really runs (position-major rows on small maps skip padding taps)
+        plan = (ctypes.c_int32 * 8)()
+        lib.gim_conv_launch_plan(sh, 0, ctypes.cast(plan, ctypes.c_void_p))
+        sf = 1.0 - (plan[7] >> 8) / 1000.0
+        lib.gim_conv_launch_plan(sh, 1, ctypes.cast(plan, ctypes.c_void_p))
+        sd = 1.0 - (plan[7] >> 8) / 1000.0
         total = cnt * t_f + n_dx * t_d + n_dw * t_w
         tot["fwd"] += cnt * t_f
         tot["dgrad"] += n_dx * t_d
         tot["wgrad"] += n_dw * t_w
-        tot["gflop"] += flops * (cnt + n_dx + n_dw) / 1e9
+        tot["gflop"] += flops * (cnt * sf + n_dx * sd + n_dw) / 1e9
         tot["algo"] += algo * (cnt + n_dx + n_dw) / 1e9
-        rows.append((total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns))
+        rows.append((total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns, sf, sd))
     rows.sort(reverse=True)
     print("%-46s %4s %4s %4s %8s | %8s %6s | %8s %6s | %8s %6s %4s | %8s" %
           ("N,H,W,Cin,Cout,K,ups,slope,pool,fold", "fwd", "dx", "dw", "exe GF", "fwd ms", "TF", "dgrad ms", "TF", "wgrad ms", "TF", "S", "tot ms"))
     print("(GF = FLOPs one launch EXECUTES: the pool / sub-pixel folds run (K+1)^2 taps at a quarter of the pixels; TF = executed TFLOP/s)")
-    for total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns in rows:
-        tf = lambda t: flops / t / 1e9 if t else 0.0  # noqa: E731
-        print("%-46s %4d %4d %4d %8.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f %4d | %8.2f" %
-              (",".join(str(c) for c in cfg), cnt, n_dx, n_dw, flops / 1e9, t_f, tf(t_f), t_d, tf(t_d), t_w, tf(t_w), ns, total))
+    for total, cfg, cnt, n_dx, n_dw, flops, t_f, t_d, t_w, ns, sf, sd in rows:
+        tf = lambda t, sh_=1.0: flops * sh_ / t / 1e9 if t else 0.0  # noqa: E731
+        print("%-46s %4d %4d %4d %8.2f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f %4d | %8.2f%s" %
+              (",".join(str(c) for c in cfg), cnt, n_dx, n_dw, flops / 1e9, t_f, tf(t_f, sf), t_d, tf(t_d, sd), t_w, tf(t_w), ns, total,
+               "   (padding taps skipped: fwd runs %.0f %%, dgrad %.0f %% of its K steps)" % (100 * sf, 100 * sd) if min(sf, sd) < 1.0 else ""))
     s = tot["fwd"] + tot["dgrad"] + tot["wgrad"]
     print("sum of conv/linear kernels per step: %.1f ms (fwd %.1f, dgrad %.1f, wgrad %.1f); executed %.0f GFLOP -> %.1f TFLOP/s = %.3f of the "
           "fp32 MFMA peak (algorithmic, unfused ops at full resolution: %.0f GFLOP -> %.1f TFLOP/s)"
