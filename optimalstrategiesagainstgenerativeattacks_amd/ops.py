@@ -694,9 +694,10 @@ def _transposed(lib, w, wk, Cout, Cin, KF, xfold=0, rows=False, subpix=False):
 
 def _xfold_factor(Cin, W):
     """J of the x-folded dgrad, dividing W.  Cin <= 4: J = 4 -> up to 16 output columns, the 16-column MFMA tile (12 of 16 carry data
-    for RGB).  Cin = 5, 6 (the generator's 6-channel image pair): J = 4 -> 24 columns on the 32-column tile of the FULL-rate
-    v_mfma_f32_32x32x2_f32 (the 16 x 16 x 4 form runs at half the rate) - 20 % more taps (K + 3 instead of K + 1 columns) at twice
-    the matrix rate (round 4; J = 2 / 12 columns before: 9x9 64->6 0.51 ms).  Cin = 7, 8: J = 2."""
+    for RGB).  Cin = 5, 6 (the generator's 6-channel image pair): J = 4 -> 24 columns on the 32-column tile of
+    v_mfma_f32_32x32x2_f32 instead of 12 on the 16-column tile of the 16 x 16 x 4 form (the same peak rate, but twice the LDS operand
+    reads per FLOP and a quarter of the work per instruction): 20 % more taps (K + 3 instead of K + 1 columns) and still
+    0.51 -> 0.32 ms on the 9x9 64->6 gradient (round 4).  Cin = 7, 8: J = 2."""
     J = 4 if Cin <= 6 else 2
     return J if (Cin <= 8 and W % J == 0 and W // J >= 1) else 0
 
