@@ -2639,7 +2639,8 @@ extern "C" int gim_conv2d_wgrad_rows_acc(const float* dy, const float* xp, float
 // The launch a conv entry point would make for `shape`, without launching anything (tests, tools/conv_autotune.py).
 //   kind 0 = gim_conv2d_fwd, 1 = gim_conv2d_dgrad, 2 = gim_conv2d_dgrad_t, 3 = gim_conv2d_wgrad_acc
 //   out[8] = {1 if a row of the compiled-in launch table matched this shape, tile rows BM, tile columns BN,
-//             split-K factor (wgrad: pixel slices), grid x, grid y, grid z, 0 (one matrix path: the fp32 MFMA)}
+//             split-K factor (wgrad: pixel slices), grid x, grid y, grid z, loop form (0 tap-major, 1 patch-resident, 2 fp16 operands,
+//             3 direct image-layer kernel) | skipped share of the K steps in 1/1000 << 8 (position-major rows, Geo.pm)}
 extern "C" int gim_conv_launch_plan(const gim_conv_shape* s, int kind, int32_t* out) {
     GIM_CHECK_ARG(s && out && kind >= 0 && kind <= 3, "conv_launch_plan: bad args");
     float* const fake = reinterpret_cast<float*>(uintptr_t(4096));   // aligned, never dereferenced: nothing is launched
