@@ -286,15 +286,16 @@ def test_conv_pair_with_activated_storage(N, C1, C2, H, expect_act):
         assert relerr(got.double().cpu(), ref) < TOL, nm
 
 
-def test_conv2d_residual_upsampled():
+@pytest.mark.parametrize("N,Cin,Cout,H", [(2, 16, 24, 8), (40, 32, 48, 4), (33, 16, 64, 2)])   # the last two: position-major rows (Geo.pm)
+def test_conv2d_residual_upsampled(N, Cin, Cout, H):
     """y = conv(x) + up2(res_low): residual stored at half resolution (skip of the up blocks)."""
     from optimalstrategiesagainstgenerativeattacks_amd import ops
-    N, Cin, Cout, K, H = 2, 16, 24, 3, 8
-    x = T(pf.normal("ru/x", (N, Cin, H, H))).requires_grad_()
-    w = T(pf.normal("ru/w", (Cout, Cin, K, K)) / 12).requires_grad_()
-    res = T(pf.normal("ru/r", (N, Cout, H // 2, H // 2))).requires_grad_()
+    K = 3
+    x = T(pf.normal("ru/x%d" % N, (N, Cin, H, H))).requires_grad_()
+    w = T(pf.normal("ru/w%d" % N, (Cout, Cin, K, K)) / 12).requires_grad_()
+    res = T(pf.normal("ru/r%d" % N, (N, Cout, H // 2, H // 2))).requires_grad_()
     y = F.conv2d(x, w, None, padding=1) + go.upsample2(res)
-    r = T(pf.uniform("ru/dy", tuple(y.shape)))
+    r = T(pf.uniform("ru/dy%d" % N, tuple(y.shape)))
     (y * r).sum().backward()
     xg, wg, rg = nhwc(x).requires_grad_(), cl_weight(w), nhwc(res).requires_grad_()
     yg = ops.conv2d(xg, wg, None, rg, None, None, None, 0, 1.0, res_ups=True)
@@ -341,7 +342,8 @@ def test_image_layer_rows_form_through_the_gradient_bucket(N, Cin, Cout, K, H, s
 
 
 @pytest.mark.parametrize("N,Cin,Cout,K,H,x_act", [(3, 32, 64, 3, 16, False), (2, 64, 128, 3, 32, True), (2, 16, 48, 3, 4, False), (5, 128, 128, 3, 2, True),
-                                                 (2, 3, 32, 3, 16, False), (2, 6, 64, 9, 16, False), (3, 48, 32, 1, 8, False)])
+                                                 (2, 3, 32, 3, 16, False), (2, 6, 64, 9, 16, False), (3, 48, 32, 1, 8, False),
+                                                 (40, 32, 64, 3, 4, True), (36, 16, 32, 3, 2, False)])   # position-major rows + the mask / pooled-skip epilogue
 def test_conv_with_pooled_skip_reader_one_autograd_node(N, Cin, Cout, K, H, x_act):
     """ops.conv2d_forkpool: y = conv(lrelu(x)) and pooled = avgpool2(x) as ONE node whose backward adds the pooled branch's gradient in
     the dgrad epilogue (gim_conv2d_dgrad_res; patch-resident and tap-major kernels, split-K maps) - or, where the dgrad takes another
