@@ -144,11 +144,21 @@ def _req(t, name):
 
 def weight_phys(w):
     """The [Cout][KH][KW][Cin] storage view of a conv weight parameter (logical [Cout,Cin,KH,KW] kept
-    channels-last), or the [out][in] linear weight itself."""
+    channels-last), or the [out][in] linear weight itself.  The view is kept on the tensor object (keyed by its data pointer: a
+    view follows in-place updates, only a re-allocated storage invalidates it) - building it costs 3 us, ~520 times per step."""
+    try:
+        c = w._gim_phys
+        if c[0] == w.data_ptr():
+            return c[1]
+    except AttributeError:
+        pass
     if w.dim() == 2:
         return w if w.is_contiguous() else w.contiguous()
     wp = w.permute(0, 2, 3, 1)
-    return wp if wp.is_contiguous() else wp.contiguous()
+    if not wp.is_contiguous():
+        return wp.contiguous()      # a copy: not cached (it would not follow updates of w)
+    w._gim_phys = (w.data_ptr(), wp)
+    return wp
 
 
 # Deterministic weight-gradient combine (slabs + fixed-order reduce) instead of float atomics, for the non-queued path
@@ -213,9 +223,16 @@ def set_matrix_path(name):
     return prev
 
 
+_SHAPES = {}   # argument tuple -> template struct (a 17-field ctypes constructor costs 1.3 us, a copy of a template 0.4; ~640 per step)
+
+
 def _shape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool=0, wfold=0, res_ups=0):
-    return GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, 0, 1 if _DETERMINISTIC[0] else 0, 0, 0, 0.0,
-                        _PREC[0] if H * W > 1 else 0)   # (linears - 1 x 1 maps - stay fp32: tiny, and the head's logits are built there)
+    key = (N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, _DETERMINISTIC[0], _PREC[0])
+    t = _SHAPES.get(key)
+    if t is None:
+        t = _SHAPES[key] = GimConvShape(N, H, W, Cin, Cout, KH, ups, pre_slope, pool, wfold, res_ups, 0, 1 if _DETERMINISTIC[0] else 0, 0, 0, 0.0,
+                                        _PREC[0] if H * W > 1 else 0)   # (linears - 1 x 1 maps - stay fp32: tiny, and the head's logits are built there)
+    return GimConvShape.from_buffer_copy(t)    # callers set tune_* / post_slope / out_zeroed on their own copy
 
 
 # Launch overrides for tools/step_autotune.py (tuning the launch table against the time of the WHOLE overlapped step instead of
@@ -535,7 +552,7 @@ class ConvFn(Function):
         _tuned(sh, "fwd", key)
         # post_slope != 1: store lrelu(y) for a consumer that is the ONLY reader of y and runs with x_act.  conv2d_post_act has
         # resolved it (1.0 when the launch splits K: the slices combine by addition); a split-K launch refuses it here
-        merged = _merged_subpixel(x, w, ups, res, sh)
+        merged = bool(ups) and _merged_subpixel(x, w, ups, res, sh)
         if post_slope != 1.0 and not merged:
             if x.dim() != 4 or _splits_k(sh, 0, key):
                 raise RuntimeError("conv: an activated output (post_slope) cannot be combined with a split-K launch or a linear layer")
@@ -772,7 +789,6 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st, x
             check(ns, "conv2d_wgrad_slabs")
     K = KH * KH * Cin
     KFF = (KH + 1) * (KH + 1) * Cin if fold else K
-    dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
     slab_bias = want_b and not (fold and ups)  # the role-swapped sub-pixel wgrad does not stream dy as its A operand
     # Megatron-style direct accumulation: when the parameter's .grad already exists as a dense buffer in the
     # weight's own memory order (FusedAdam's flat gradient bucket) and no higher-order graph is being built,
@@ -807,6 +823,7 @@ def _conv_wgrad(lib, dy, x, w, wp, bias, sigma, u_s, v_s, sh, cfg, want_b, st, x
                 db = torch.empty(Cout, device=dev, dtype=torch.float32)
                 check(lib.gim_colsum(_p(dy), _p(db), _p(scr), Mo, Cout, st), "colsum")
         return None, db
+    dwp = torch.empty(Cout * K, device=dev, dtype=torch.float32)
     if want_b and acc_b is None:
         db = torch.empty(Cout, device=dev, dtype=torch.float32)
     if ns == 1 and sigma is None and not fold and acc_w is None:
@@ -872,14 +889,26 @@ class ConvDgradFn(Function):
 
 
 def _grad_target(p):
-    """The parameter's existing .grad as a flat buffer in the parameter's own memory order, or None."""
+    """The parameter's existing .grad as a flat buffer in the parameter's own memory order, or None.  (The checked view is kept
+    on the gradient tensor, keyed by its data pointer - FusedAdam's gradients are fixed views of its flat bucket.)"""
     if p is None:
         return None
     g = p.grad
-    if g is None or not g.is_cuda or g.dtype != torch.float32 or g.shape != p.shape:
+    if g is None:
+        return None
+    try:
+        c = g._gim_tgt
+        if c[0] == g.data_ptr():
+            return c[1]
+    except AttributeError:
+        pass
+    if not g.is_cuda or g.dtype != torch.float32 or g.shape != p.shape:
         return None
     gp = g.permute(0, 2, 3, 1) if g.dim() == 4 else g
-    return gp if gp.is_contiguous() else None
+    if not gp.is_contiguous():
+        return None
+    g._gim_tgt = (g.data_ptr(), gp)
+    return gp
 
 
 def _req_w(w):
