@@ -314,6 +314,19 @@ class AdaInImage2Image(nn.Module):
         return self.adain_up_block(x=x, style=style, svs=svs_up)
 
 
+def _set_training(module, mode):
+    """nn.Module.train(mode) for a whole model in a third of the time: the same walk over self.modules(), with `training` written
+    straight into each module's __dict__ instead of through 220 recursive train() calls and nn.Module.__setattr__'s type checks
+    (the reference calls .train() on both networks at the start of every training step, training/gim_img_training.py:160,170:
+    0.65 + 0.2 ms of host time per step)."""
+    if not isinstance(mode, bool):
+        raise ValueError("training mode is expected to be boolean")
+    for m in module.modules():
+        m.__dict__["training"] = mode
+    return module
+
+
+
 class GIMFaceDis(nn.Module):
     """models/gim_img_models.py:263-299."""
 
@@ -353,6 +366,9 @@ class GIMFaceAuthenticator(nn.Module):
         self.env_encoder = env_encoder
         self.dis = dis
         self._sn_plan = None
+
+    def train(self, mode=True):
+        return _set_training(self, mode)
 
     def prefetch_spectral(self, rounds):
         """Run the power iterations of the next `rounds` calls of each encoder up front (mb.SNPlan)."""
@@ -416,6 +432,9 @@ class GIMFaceImpersonator(nn.Module):
         self.use_img_att = use_img_att
         self.img_att = mb.ImgAttention(img1_channels=self.src_encoder.img_channels, img2_channels=self.img2img.out_channels)
         self._sn_plan = None
+
+    def train(self, mode=True):
+        return _set_training(self, mode)
 
     def forward(self, leaked_sample, n, remove_noise_mean=True, z=None):
         if self._sn_plan is None:

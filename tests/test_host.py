@@ -492,3 +492,17 @@ def test_training_step_runs_autograd_nodes_on_the_calling_thread():
         (x * 2).sum().backward()
         assert torch.equal(x.grad, torch.full((3,), 2.0))
     assert torch.autograd.is_multithreading_enabled() == before
+
+
+def test_model_train_eval_switch_every_submodule():
+    """GIMFaceImpersonator / GIMFaceAuthenticator override train() with a direct walk (gim_img_models._set_training: the reference calls
+    .train() on both networks every step): same contract as nn.Module.train - every submodule switched, eval() = train(False), a
+    non-boolean mode refused, self returned."""
+    import optimalstrategiesagainstgenerativeattacks_amd as G
+    for net in (G.get_im(16, 1, 32), G.get_au(16, 1, 32)):
+        assert net.eval() is net and not any(m.training for m in net.modules())
+        assert net.train() is net and all(m.training for m in net.modules())
+        net.train(False)
+        assert not any(m.training for m in net.modules())
+        with pytest.raises(ValueError):
+            net.train("yes")

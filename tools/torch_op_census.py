@@ -1,6 +1,6 @@
 """Which torch (ATen) operators launch kernels of their own inside one training iteration - the fills, adds and copies that are
 not this package's HIP kernels - with counts per step and the Python frames that issue them.
-    python tools/torch_op_census.py [episodes=16]"""
+    python tools/torch_op_census.py [episodes=16] [reg_param=0]"""
 import collections
 import os
 import sys
@@ -16,7 +16,8 @@ dev = torch.device("cuda:0")
 u = bench.UNIT["vox64"]
 m, n, k = 1, 5, 10
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-G, tr = bench.build_trainer(u["S"], u["C"], n, m, k, dev)
+REG = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+G, tr = bench.build_trainer(u["S"], u["C"], n, m, k, dev, reg_param=REG)
 trainer = G.DataParallelMock(tr)
 leaked, real, si = bench.synthetic_batch(B, m, n, k, u["C"], u["S"], dev, 1)
 for _ in range(3):
